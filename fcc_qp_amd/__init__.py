@@ -1,0 +1,33 @@
+"""fcc_qp_amd -- MI355X-native batched ADMM friction-cone QP solver (drop-in for fcc_qp).
+
+Python surface of the reference (``/root/reference/src/main.cpp:19-56``, re-exported by
+``/root/reference/fcc_qp/__init__.py:1``): ``FCCQP, FCCQPOptions, FCCQPSolution, FCCQPDetails``
+with identical attribute, method and keyword names -- plus ``FCCQPBatch`` for solving thousands of
+independent QPs in one kernel launch.  Everything numeric runs in hand-written HIP kernels for
+gfx950 behind the C ABI of ``include/fccqp.h``; there is NO CPU fallback: if the extension is not
+built, importing this package raises, and without a GPU constructing a solver raises.
+"""
+from __future__ import annotations
+
+import os as _os
+
+_HERE = _os.path.dirname(_os.path.abspath(__file__))
+
+try:
+    from .fcc_qp_solver import (  # noqa: F401
+        FCCQP, FCCQPBatch, FCCQPBatchSolution, FCCQPDetails, FCCQPError, FCCQPOptions, FCCQPSolution,
+        device_count, KERNEL_AUTO, KERNEL_FUSED, KERNEL_GENERIC, FLAG_ADMM_NUMERICAL,
+        FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_NUMERICAL, FLAG_PRESOLVE_RAN)
+except ImportError as exc:  # fail loudly: the HIP extension IS the product
+    raise ImportError(
+        "fcc_qp_amd: the native extension (fcc_qp_amd/libfccqp_hip.so + fcc_qp_solver*.so) is not "
+        "built or cannot be loaded. Run `python -m fcc_qp_amd.build` (needs hipcc, gfx950). "
+        f"There is no CPU fallback. Original error: {exc}") from exc
+
+from . import problems  # noqa: E402,F401
+from .batch import solve_tensors  # noqa: E402,F401
+
+LIB_PATH = _os.path.join(_HERE, "libfccqp_hip.so")
+
+__all__ = ["FCCQP", "FCCQPBatch", "FCCQPBatchSolution", "FCCQPDetails", "FCCQPError", "FCCQPOptions",
+           "FCCQPSolution", "device_count", "problems", "solve_tensors", "LIB_PATH"]

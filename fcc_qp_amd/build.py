@@ -1,0 +1,87 @@
+"""In-tree build of the native pieces (no cmake needed):
+
+  fcc_qp_amd/libfccqp_hip.so        HIP kernels for gfx950 + the C ABI of include/fccqp.h  (hipcc)
+  fcc_qp_amd/fcc_qp_solver.*.so     pybind11 module with the reference's Python surface     (g++)
+
+The reference builds the same two layers with CMake (CMakeLists.txt:32-40: static lib fcc_qplib +
+pybind11 module fcc_qp_solver); here the library is the HIP path instead of Eigen.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+from typing import List
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfccqp_hip.so")
+ARCH = "gfx950"
+
+
+def _ext_suffix() -> str:
+    return sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+
+
+PYMOD = os.path.join(HERE, "fcc_qp_solver" + _ext_suffix())
+
+
+def _newer(target: str, deps: List[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _run(cmd: List[str]) -> None:
+    print("[build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
+
+
+def build_lib(force: bool = False) -> str:
+    srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip")]
+    deps = srcs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
+                   os.path.join(ROOT, "include", "fccqp.h")]
+    if force or _newer(LIB, deps):
+        objs = []
+        for src in srcs:
+            obj = os.path.splitext(src)[0] + ".o"
+            if force or _newer(obj, deps):
+                _run([hipcc(), "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+                      "-fgpu-rdc" if False else "-fno-gpu-rdc", "-ffp-contract=off",
+                      "-Wall", "-Wno-unused-function", "-c", src, "-o", obj])
+            objs.append(obj)
+        _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+    return LIB
+
+
+def build_pymod(force: bool = False) -> str:
+    import pybind11
+
+    srcs = [os.path.join(CSRC, f) for f in ("pybind_module.cpp", "fcc_qp.cpp")]
+    deps = srcs + [os.path.join(CSRC, "fcc_qp.hpp"), os.path.join(ROOT, "include", "fccqp.h"), LIB]
+    if force or _newer(PYMOD, deps):
+        inc = [f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
+               f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall"] + inc + srcs +
+             ["-o", PYMOD, f"-L{HERE}", "-lfccqp_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+    return PYMOD
+
+
+def build_all(force: bool = False) -> None:
+    build_lib(force)
+    build_pymod(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,430 @@
+// fccqp_capi.cpp -- implementation of the C ABI in include/fccqp.h on top of the gfx950 kernels.
+//
+// Replaces the body of the reference class fcc_qp::FCCQP (src/fcc_qp.cpp:24-207): the handle owns
+// the device-resident workspace and warm-start state that the reference keeps in Eigen members
+// (src/fcc_qp.hpp:135-171), one slice per instance of the batch.
+// Compiled by hipcc (host side only; kernels live in the .hip files).
+#include "../../include/fccqp.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fccqp_device.h"
+
+struct fccqp_solver {
+  int n = 0, m = 0, nc = 0, s = 0, batch = 0, device = 0;
+  fccqp_options opt{1000, 1e-6, 1e-3, 1e-6};  // reference defaults, src/fcc_qp.hpp:30-35
+  bool warm_start = false;                    // src/fcc_qp.hpp:133
+  int kernel_request = FCCQP_KERNEL_AUTO;
+  int kernel_used = FCCQP_KERNEL_GENERIC;
+  bool solved = false;
+  bool last_was_warm = false;
+  double last_solve_wall = 0.0;
+  size_t lds_limit = 64 * 1024;
+  hipStream_t stream = nullptr;      // the solver's own stream
+  hipStream_t last_stream = nullptr; // stream of the last enqueue
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // staged inputs (host-pointer solve)
+  double *dQ = nullptr, *db = nullptr, *dA = nullptr, *dbeq = nullptr, *dmu = nullptr,
+         *dlb = nullptr, *dub = nullptr;
+  // state / outputs
+  double *dx = nullptr, *dmux = nullptr, *dmulc = nullptr, *dmetrics = nullptr, *dwork = nullptr;
+  int *dniter = nullptr, *dflags = nullptr;
+  long long *dticks = nullptr;
+  long long work_stride = 0;
+  std::string err;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int fail(fccqp_solver *s, int code, const char *what, hipError_t e = hipSuccess) {
+  if (s) {
+    char buf[512];
+    if (e != hipSuccess)
+      std::snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+    else
+      std::snprintf(buf, sizeof buf, "%s", what);
+    s->err = buf;
+  }
+  return code;
+}
+
+#define HIP_TRY(s, call)                                            \
+  do {                                                              \
+    hipError_t e_ = (call);                                         \
+    if (e_ != hipSuccess) return fail((s), FCCQP_ERR_HIP, #call, e_); \
+  } while (0)
+
+template <class T>
+hipError_t dmalloc(T **p, size_t count) {
+  return hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T));
+}
+
+size_t n_mu(const fccqp_solver *s) { return (size_t)(s->nc / 3); }
+
+int ensure_staging(fccqp_solver *s) {
+  if (s->dQ) return FCCQP_OK;
+  const size_t B = (size_t)s->batch, n = (size_t)s->n, m = (size_t)s->m;
+  HIP_TRY(s, dmalloc(&s->dQ, B * n * n));
+  HIP_TRY(s, dmalloc(&s->db, B * n));
+  HIP_TRY(s, dmalloc(&s->dA, B * m * n));
+  HIP_TRY(s, dmalloc(&s->dbeq, B * m));
+  HIP_TRY(s, dmalloc(&s->dmu, B * n_mu(s)));
+  HIP_TRY(s, dmalloc(&s->dlb, B * n));
+  HIP_TRY(s, dmalloc(&s->dub, B * n));
+  return FCCQP_OK;
+}
+
+int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *dA,
+            const double *dbeq, const double *dmu, const double *dlb, const double *dub,
+            hipStream_t stream) {
+  fccqp::KernelArgs a{};
+  a.n = s->n; a.m = s->m; a.nc = s->nc; a.s = s->s; a.batch = s->batch;
+  a.warm_start = s->warm_start ? 1 : 0;
+  a.max_iter = s->opt.max_iter; a.rho = s->opt.rho;
+  a.eps_fcone = s->opt.eps_fcone; a.eps_bound = s->opt.eps_bound;
+  a.Q = dQ; a.b = db; a.A = dA; a.b_eq = dbeq; a.mu = dmu; a.lb = dlb; a.ub = dub;
+  a.x = s->dx; a.mu_x = s->dmux; a.mu_lc = s->dmulc;
+  a.n_iter = s->dniter; a.flags = s->dflags; a.metrics = s->dmetrics;
+  a.factor_ticks = s->dticks; a.workspace = s->dwork; a.workspace_stride = s->work_stride;
+
+  const bool want_fused = s->kernel_request != FCCQP_KERNEL_GENERIC;
+  const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s);
+  if (s->kernel_request == FCCQP_KERNEL_FUSED && !can_fuse)
+    return fail(s, FCCQP_ERR_UNSUPPORTED, "no fused kernel is compiled for this shape");
+  HIP_TRY(s, hipEventRecord(s->ev0, stream));
+  hipError_t e;
+  if (want_fused && can_fuse) {
+    s->kernel_used = FCCQP_KERNEL_FUSED;
+    e = fccqp::launch_fused(a, stream);
+  } else {
+    s->kernel_used = FCCQP_KERNEL_GENERIC;
+    e = fccqp::launch_generic(a, s->lds_limit, stream);
+  }
+  if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "kernel launch", e);
+  HIP_TRY(s, hipEventRecord(s->ev1, stream));
+  s->last_stream = stream;
+  s->last_was_warm = s->warm_start;
+  s->solved = true;
+  return FCCQP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fccqp_version(void) { return FCCQP_VERSION_MAJOR * 100 + FCCQP_VERSION_MINOR; }
+
+const char *fccqp_strerror(int code) {
+  switch (code) {
+    case FCCQP_OK: return "ok";
+    case FCCQP_ERR_INVALID_ARG: return "invalid argument";
+    case FCCQP_ERR_SHAPE: return "invalid problem sizes";
+    case FCCQP_ERR_NO_DEVICE: return "no HIP device available (this library has no CPU path)";
+    case FCCQP_ERR_HIP: return "HIP runtime error";
+    case FCCQP_ERR_ALLOC: return "allocation failed";
+    case FCCQP_ERR_FRICTION_COEFFS: return "fewer than nc/3 friction coefficients";
+    case FCCQP_ERR_NOT_SOLVED: return "no solve has been run";
+    case FCCQP_ERR_UNSUPPORTED: return "shape not supported by the requested kernel";
+    default: return "unknown error";
+  }
+}
+
+int fccqp_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int fccqp_default_options(fccqp_options *opt) {
+  if (!opt) return FCCQP_ERR_INVALID_ARG;
+  *opt = fccqp_options{1000, 1e-6, 1e-3, 1e-6};
+  return FCCQP_OK;
+}
+
+int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_c_start, int batch,
+                 int device, fccqp_solver **out) {
+  if (!out) return FCCQP_ERR_INVALID_ARG;
+  *out = nullptr;
+  // reference asserts, src/fcc_qp.cpp:29-33
+  if (num_vars < 0 || num_equality_constraints < 0 || nc < 0 || nc % 3 != 0 ||
+      lambda_c_start < 0 || lambda_c_start + nc > num_vars || batch < 1)
+    return FCCQP_ERR_SHAPE;
+  if (num_vars + num_equality_constraints > fccqp::kGenericMaxN) return FCCQP_ERR_UNSUPPORTED;
+  const int ndev = fccqp_device_count();
+  if (ndev <= 0 || device < 0 || device >= ndev) return FCCQP_ERR_NO_DEVICE;
+
+  fccqp_solver *s = new (std::nothrow) fccqp_solver();
+  if (!s) return FCCQP_ERR_ALLOC;
+  s->n = num_vars; s->m = num_equality_constraints; s->nc = nc; s->s = lambda_c_start;
+  s->batch = batch; s->device = device;
+  DeviceGuard g(device);
+  if (!g.ok) { delete s; return FCCQP_ERR_NO_DEVICE; }
+
+  int rc = [&]() -> int {
+    hipDeviceProp_t prop;
+    HIP_TRY(s, hipGetDeviceProperties(&prop, device));
+    size_t lds = prop.sharedMemPerBlock;               // 64 KiB default limit
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess &&
+        (size_t)optin > lds)
+      lds = (size_t)optin;                              // 160 KiB on gfx950
+    s->lds_limit = lds;
+    HIP_TRY(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(s, hipEventCreate(&s->ev0));
+    HIP_TRY(s, hipEventCreate(&s->ev1));
+    const size_t B = (size_t)batch, n = (size_t)num_vars;
+    HIP_TRY(s, dmalloc(&s->dx, B * n));
+    HIP_TRY(s, dmalloc(&s->dmux, B * n));
+    HIP_TRY(s, dmalloc(&s->dmulc, B * (size_t)nc));
+    HIP_TRY(s, dmalloc(&s->dmetrics, 4 * B));
+    HIP_TRY(s, dmalloc(&s->dniter, B));
+    HIP_TRY(s, dmalloc(&s->dflags, B));
+    HIP_TRY(s, dmalloc(&s->dticks, B));
+    // reference ctor zero-initialises x_, mu_x_, mu_lambda_c_ (src/fcc_qp.cpp:48-53)
+    HIP_TRY(s, hipMemset(s->dx, 0, sizeof(double) * (B * n ? B * n : 1)));
+    HIP_TRY(s, hipMemset(s->dmux, 0, sizeof(double) * (B * n ? B * n : 1)));
+    HIP_TRY(s, hipMemset(s->dmulc, 0, sizeof(double) * (B * nc ? B * nc : 1)));
+    HIP_TRY(s, hipMemset(s->dmetrics, 0, sizeof(double) * 4 * B));
+    HIP_TRY(s, hipMemset(s->dniter, 0, sizeof(int) * B));
+    HIP_TRY(s, hipMemset(s->dflags, 0, sizeof(int) * B));
+    HIP_TRY(s, hipMemset(s->dticks, 0, sizeof(long long) * B));
+    s->work_stride = fccqp::generic_workspace_doubles(num_vars, num_equality_constraints, nc, lds);
+    if (s->work_stride > 0) HIP_TRY(s, dmalloc(&s->dwork, B * (size_t)s->work_stride));
+    return FCCQP_OK;
+  }();
+  if (rc != FCCQP_OK) {
+    std::fprintf(stderr, "fccqp_create: %s\n", s->err.c_str());
+    fccqp_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return FCCQP_OK;
+}
+
+int fccqp_destroy(fccqp_solver *s) {
+  if (!s) return FCCQP_OK;
+  DeviceGuard g(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  void *ptrs[] = {s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, s->dx, s->dmux, s->dmulc,
+                  s->dmetrics, s->dwork, s->dniter, s->dflags, s->dticks};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return FCCQP_OK;
+}
+
+const char *fccqp_last_error(const fccqp_solver *s) { return s ? s->err.c_str() : "null handle"; }
+
+int fccqp_set_options(fccqp_solver *s, const fccqp_options *opt) {
+  if (!s || !opt) return FCCQP_ERR_INVALID_ARG;
+  s->opt = *opt;  // set_options copies blindly, src/fcc_qp.hpp:85-87
+  return FCCQP_OK;
+}
+int fccqp_get_options(const fccqp_solver *s, fccqp_options *opt) {
+  if (!s || !opt) return FCCQP_ERR_INVALID_ARG;
+  *opt = s->opt;
+  return FCCQP_OK;
+}
+int fccqp_set_warm_start(fccqp_solver *s, int warm_start) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  s->warm_start = warm_start != 0;
+  return FCCQP_OK;
+}
+int fccqp_set_kernel(fccqp_solver *s, int kernel) {
+  if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_FUSED) return FCCQP_ERR_INVALID_ARG;
+  s->kernel_request = kernel;
+  return FCCQP_OK;
+}
+int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {
+  if (!s || !kernel_in_use) return FCCQP_ERR_INVALID_ARG;
+  const bool fuse = s->kernel_request != FCCQP_KERNEL_GENERIC &&
+                    fccqp::fused_supported(s->n, s->m, s->nc, s->s);
+  *kernel_in_use = fuse ? FCCQP_KERNEL_FUSED : FCCQP_KERNEL_GENERIC;
+  return FCCQP_OK;
+}
+int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc, int *lambda_c_start,
+                    int *batch, int *device) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  if (num_vars) *num_vars = s->n;
+  if (num_eq) *num_eq = s->m;
+  if (nc) *nc = s->nc;
+  if (lambda_c_start) *lambda_c_start = s->s;
+  if (batch) *batch = s->batch;
+  if (device) *device = s->device;
+  return FCCQP_OK;
+}
+
+int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
+                const double *b_eq, const double *friction_coeffs, int n_friction,
+                const double *lb, const double *ub) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  const size_t B = (size_t)s->batch, n = (size_t)s->n, m = (size_t)s->m, nm = n_mu(s);
+  if ((n && (!Q || !b || !lb || !ub)) || (m && n && !A_eq) || (m && !b_eq) || (nm && !friction_coeffs))
+    return fail(s, FCCQP_ERR_INVALID_ARG, "null input pointer");
+  if (n_friction < (int)nm) return fail(s, FCCQP_ERR_FRICTION_COEFFS, "friction_coeffs too short");
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(s, FCCQP_ERR_NO_DEVICE, "hipSetDevice failed");
+  int rc = ensure_staging(s);
+  if (rc != FCCQP_OK) return rc;
+  hipStream_t st = s->stream;
+  HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(double) * B * n * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(s, hipMemcpyAsync(s->db, b, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+  if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(double) * B * m * n, hipMemcpyHostToDevice, st));
+  if (m) HIP_TRY(s, hipMemcpyAsync(s->dbeq, b_eq, sizeof(double) * B * m, hipMemcpyHostToDevice, st));
+  if (nm) {
+    if ((size_t)n_friction == nm) {
+      HIP_TRY(s, hipMemcpyAsync(s->dmu, friction_coeffs, sizeof(double) * B * nm, hipMemcpyHostToDevice, st));
+    } else {  // keep the first nc/3 of every instance's row
+      HIP_TRY(s, hipMemcpy2DAsync(s->dmu, sizeof(double) * nm, friction_coeffs,
+                                  sizeof(double) * (size_t)n_friction, sizeof(double) * nm, B,
+                                  hipMemcpyHostToDevice, st));
+    }
+  }
+  HIP_TRY(s, hipMemcpyAsync(s->dlb, lb, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(s, hipMemcpyAsync(s->dub, ub, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+  rc = enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st);
+  if (rc != FCCQP_OK) return rc;
+  HIP_TRY(s, hipStreamSynchronize(st));
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  s->last_solve_wall = std::chrono::duration<double>(t1 - t0).count();  // src/fcc_qp.cpp:188-190
+  return FCCQP_OK;
+}
+
+int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, const double *dA_eq,
+                       const double *db_eq, const double *dfriction, const double *dlb,
+                       const double *dub, void *stream) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  const size_t n = (size_t)s->n, m = (size_t)s->m, nm = n_mu(s);
+  if ((n && (!dQ || !db || !dlb || !dub)) || (m && n && !dA_eq) || (m && !db_eq) || (nm && !dfriction))
+    return fail(s, FCCQP_ERR_INVALID_ARG, "null device pointer");
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(s, FCCQP_ERR_NO_DEVICE, "hipSetDevice failed");
+  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : s->stream;
+  s->last_solve_wall = 0.0;
+  return enqueue(s, dQ, db, dA_eq, db_eq, dfriction, dlb, dub, st);
+}
+
+int fccqp_synchronize(fccqp_solver *s) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  DeviceGuard g(s->device);
+  if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  return FCCQP_OK;
+}
+
+int fccqp_get_solution(fccqp_solver *s, double *z, fccqp_details *details) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  if (!s->solved) return fail(s, FCCQP_ERR_NOT_SOLVED, "GetSolution before Solve");
+  DeviceGuard g(s->device);
+  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  const size_t B = (size_t)s->batch, n = (size_t)s->n;
+  if (z && n) HIP_TRY(s, hipMemcpy(z, s->dx, sizeof(double) * B * n, hipMemcpyDeviceToHost));
+  if (details) {
+    std::vector<int> it(B), fl(B);
+    std::vector<double> met(4 * B);
+    std::vector<long long> tk(B);
+    HIP_TRY(s, hipMemcpy(it.data(), s->dniter, sizeof(int) * B, hipMemcpyDeviceToHost));
+    HIP_TRY(s, hipMemcpy(fl.data(), s->dflags, sizeof(int) * B, hipMemcpyDeviceToHost));
+    HIP_TRY(s, hipMemcpy(met.data(), s->dmetrics, sizeof(double) * 4 * B, hipMemcpyDeviceToHost));
+    HIP_TRY(s, hipMemcpy(tk.data(), s->dticks, sizeof(long long) * B, hipMemcpyDeviceToHost));
+    double wall = s->last_solve_wall;
+    if (wall == 0.0) {  // device-pointer solve: report the kernel time instead
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) wall = 1e-3 * (double)ms;
+    }
+    for (size_t i = 0; i < B; ++i) {
+      fccqp_details &d = details[i];
+      d.n_iter = it[i];
+      d.admm_residual_bounds = met[0 * B + i];
+      d.admm_residual_friction_cone = met[1 * B + i];
+      d.bounds_viol = met[2 * B + i];
+      d.friction_cone_viol = met[3 * B + i];
+      d.solve_time = wall;
+      d.factorization_time = 1e-8 * (double)tk[i];  // wall_clock64() ticks at 100 MHz
+      // src/fcc_qp.cpp:203-204
+      d.solve_status = (it[i] == s->opt.max_iter) ? FCCQP_STATUS_MAX_ITERATIONS : FCCQP_STATUS_SUCCESS;
+      d.flags = fl[i];
+    }
+  }
+  return FCCQP_OK;
+}
+
+int fccqp_get_solution_device(fccqp_solver *s, const double **z, const int **n_iter,
+                              const int **flags, const double **metrics,
+                              const long long **factor_ticks) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  if (!s->solved) return fail(s, FCCQP_ERR_NOT_SOLVED, "GetSolution before Solve");
+  if (z) *z = s->dx;
+  if (n_iter) *n_iter = s->dniter;
+  if (flags) *flags = s->dflags;
+  if (metrics) *metrics = s->dmetrics;
+  if (factor_ticks) *factor_ticks = s->dticks;
+  return FCCQP_OK;
+}
+
+int fccqp_get_state(fccqp_solver *s, double *x, double *mu_x, double *mu_lambda_c) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  DeviceGuard g(s->device);
+  if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  const size_t B = (size_t)s->batch, n = (size_t)s->n, nc = (size_t)s->nc;
+  if (x && n) HIP_TRY(s, hipMemcpy(x, s->dx, sizeof(double) * B * n, hipMemcpyDeviceToHost));
+  if (mu_x && n) HIP_TRY(s, hipMemcpy(mu_x, s->dmux, sizeof(double) * B * n, hipMemcpyDeviceToHost));
+  if (mu_lambda_c && nc)
+    HIP_TRY(s, hipMemcpy(mu_lambda_c, s->dmulc, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
+  return FCCQP_OK;
+}
+
+int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x, const double *mu_lambda_c) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  DeviceGuard g(s->device);
+  if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  const size_t B = (size_t)s->batch, n = (size_t)s->n, nc = (size_t)s->nc;
+  if (x && n) HIP_TRY(s, hipMemcpy(s->dx, x, sizeof(double) * B * n, hipMemcpyHostToDevice));
+  if (mu_x && n) HIP_TRY(s, hipMemcpy(s->dmux, mu_x, sizeof(double) * B * n, hipMemcpyHostToDevice));
+  if (mu_lambda_c && nc)
+    HIP_TRY(s, hipMemcpy(s->dmulc, mu_lambda_c, sizeof(double) * B * nc, hipMemcpyHostToDevice));
+  return FCCQP_OK;
+}
+
+int fccqp_last_kernel_ms(fccqp_solver *s, float *ms) {
+  if (!s || !ms) return FCCQP_ERR_INVALID_ARG;
+  if (!s->solved) return fail(s, FCCQP_ERR_NOT_SOLVED, "no solve has been run");
+  DeviceGuard g(s->device);
+  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return FCCQP_OK;
+}
+
+int fccqp_algorithmic_bytes(const fccqp_solver *s, long long *bytes) {
+  if (!s || !bytes) return FCCQP_ERR_INVALID_ARG;
+  const long long n = s->n, m = s->m, nc = s->nc, B = s->batch;
+  long long elems = n * n + m * n + 4 * n + m + nc / 3;
+  if (s->warm_start) elems += 2 * (2 * n + nc);               // state read + written
+  *bytes = 8 * B * elems;
+  return FCCQP_OK;
+}
+
+}  // extern "C"

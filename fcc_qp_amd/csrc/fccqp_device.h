@@ -1,0 +1,49 @@
+// fccqp_device.h -- kernel argument block and launch entry points shared by the C ABI
+// implementation (fccqp_capi.cpp) and the gfx950 kernels (*.hip).  Internal header.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fccqp {
+
+// One block of arguments for every kernel variant.  All pointers are device pointers,
+// instance-major (see include/fccqp.h).
+struct KernelArgs {
+  int n;        // num_vars                      (reference fcc_qp.hpp:128)
+  int m;        // num_equality_constraints      (:131)
+  int nc;       // contact force variables       (:129)
+  int s;        // lambda_c_start                (:130)
+  int batch;
+  int warm_start;                               // (:133)
+  int max_iter;                                 // FCCQPOptions (:30-35)
+  double rho, eps_fcone, eps_bound;
+  const double *Q, *b, *A, *b_eq, *mu, *lb, *ub;
+  // warm-start state, also the outputs: x doubles as z (reference GetSolution: z = x_, cpp:205)
+  double *x, *mu_x, *mu_lc;
+  int *n_iter;            // [batch]
+  int *flags;             // [batch]  FCCQP_FLAG_*
+  double *metrics;        // [4][batch] residual_bounds, residual_cone, bounds_viol, cone_viol
+  long long *factor_ticks;  // [batch] 100 MHz ticks spent factorising
+  double *workspace;      // generic kernel, large shapes: per-block packed KKT in global memory
+  long long workspace_stride;  // doubles per block
+};
+
+// flag bits (mirror include/fccqp.h)
+constexpr int kFlagPresolveRan = 1;
+constexpr int kFlagPresolveNumerical = 2;
+constexpr int kFlagAdmmNumerical = 4;
+constexpr int kFlagEqualityOnly = 8;
+
+// ---- generic kernel (fccqp_generic.hip) -----------------------------------------------------
+// Largest KKT size N = n + m the generic kernel handles (8 register slots x 64 lanes).
+constexpr int kGenericMaxN = 512;
+// Bytes of dynamic LDS the generic kernel needs when the packed KKT lives in LDS.
+size_t generic_lds_bytes(int n, int m, int nc);
+// Doubles of global workspace per block when the packed KKT does not fit in LDS (else 0).
+long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit);
+hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream);
+
+// ---- fused shape-specialised kernels (fccqp_fused.hip) ---------------------------------------
+bool fused_supported(int n, int m, int nc, int s);
+hipError_t launch_fused(const KernelArgs &a, hipStream_t stream);
+
+}  // namespace fccqp

@@ -1,0 +1,424 @@
+// fccqp_generic.hip -- shape-generic gfx950 kernel: ONE WAVEFRONT (64 lanes) PER QP INSTANCE.
+//
+// Hot path replaced (reference /root/reference):
+//   FCCQP::Solve   src/fcc_qp.cpp:114-191   (assemble KKT, presolve, epilogue metrics)
+//   FCCQP::DoADMM  src/fcc_qp.cpp:57-112    (rho-shifted factorisation + ADMM loop)
+//   projections    src/constraint_utils.cpp:5-65
+//   Eigen::LDLT compute/solve at the call sites fcc_qp.cpp:68,86,161,174
+//
+// Design (MI355X): a workgroup is one wavefront, so no barrier is ever needed.  The KKT matrix
+// [[Q(+rho I), A^T],[A, 0]] is assembled once into LDS as a packed lower triangle
+// (column-major, column j holds rows j..N-1 contiguously, so a lane-per-row sweep of a column is
+// bank-conflict free) and factorised in place by an unpivoted LDL^T in natural order.  The matrix
+// is symmetric quasi-definite for rho > 0 / Q > 0, so every symmetric pivot order exists; the
+// reference's Eigen LDLT pivots by the largest remaining diagonal entry, which only reorders the
+// same block elimination -- results agree to ~1e-13 relative (tests/test_numerics_choice.py).
+// All vectors (rhs, x, duals, bounds) live in registers, lane i owning entries i, i+64, ...
+// Shapes whose packed KKT exceeds the LDS budget spill the matrix to a per-block global
+// workspace (same code path through a generic pointer).
+//
+// This is the any-shape path and the first correct HIP path; the shape-specialised kernel in
+// fccqp_fused.hip is the fast one.
+#include "fccqp_device.h"
+
+#include <cfloat>
+
+namespace fccqp {
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ void wave_sync() {
+  // Single-wave workgroup: LDS/global accesses of one wave execute in program order; the fence
+  // keeps the compiler from reordering cross-lane producer/consumer accesses.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  // src_lane is wave-uniform
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_xor(v, off, kWave);
+    v = (v < o) ? o : v;  // std::max(v, o)
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double o = __shfl_xor(v, off, kWave);
+    v = (o < v) ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// packed lower, column-major: element (i,j), i >= j, at col_base(j) + i  (col_base includes -j)
+__device__ __forceinline__ int col_base(int j, int N) { return j * N - (j * (j - 1)) / 2 - j; }
+
+// Unpivoted LDL^T in place (right-looking), natural order.  Returns true if a pivot was zero or
+// not finite (the situation in which Eigen's info() != Success can arise, fcc_qp.cpp:164).
+template <int SLOTS>
+__device__ bool ldlt_factor(double *M, int N, int lane) {
+  bool bad_any = false;
+  for (int k = 0; k < N; ++k) {
+    const int ck = col_base(k, N);
+    const double d = M[ck + k];
+    const bool bad = !(fabs(d) > 0.0) || !(fabs(d) <= DBL_MAX);
+    bad_any |= bad;
+    double l[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const int i = k + 1 + lane + kWave * t;
+      const double a = (i < N) ? M[ck + i] : 0.0;
+      l[t] = bad ? a : a / d;  // Eigen: A21 /= pivot only when the pivot is non-zero
+    }
+#pragma unroll 4
+    for (int j = k + 1; j < N; ++j) {
+      const double c = M[ck + j];  // a_jk before scaling: same address in every lane (broadcast)
+      const int cj = col_base(j, N);
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = k + 1 + lane + kWave * t;
+        if (i >= j && i < N) M[cj + i] -= l[t] * c;
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const int i = k + 1 + lane + kWave * t;
+      if (i < N) M[ck + i] = l[t];
+    }
+    wave_sync();
+  }
+  return bad_any;
+}
+
+// x := (L D L^T)^-1 x with Eigen's pseudo-inverse rule on D (|d| > DBL_MIN else 0).
+// x is lane-distributed: lane owns entries lane + 64 t.
+template <int SLOTS>
+__device__ void ldlt_solve(const double *M, int N, int lane, double (&x)[SLOTS]) {
+  // forward, unit lower, column oriented
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    for (int kk = 0; kk < kWave; ++kk) {
+      const int k = s * kWave + kk;
+      if (k >= N) break;
+      const double xk = lane_bcast(x[s], kk);
+      const int ck = col_base(k, N);
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = lane + kWave * t;
+        if (i > k && i < N) x[t] -= M[ck + i] * xk;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const int i = lane + kWave * t;
+    if (i < N) {
+      const double d = M[col_base(i, N) + i];
+      x[t] = (fabs(d) > DBL_MIN) ? x[t] / d : 0.0;
+    }
+  }
+  // backward with L^T: x_i -= L[k][i] * x_k for i < k
+#pragma unroll
+  for (int s = SLOTS - 1; s >= 0; --s) {
+    for (int kk = kWave - 1; kk >= 0; --kk) {
+      const int k = s * kWave + kk;
+      if (k >= N) continue;
+      const double xk = lane_bcast(x[s], kk);
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = lane + kWave * t;
+        if (i < k) x[t] -= M[col_base(i, N) + k] * xk;
+      }
+    }
+  }
+}
+
+// reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25
+__device__ __forceinline__ void project_cone3(double fx, double fy, double fz, double mu,
+                                              double &ox, double &oy, double &oz) {
+  const double nxy = sqrt(fx * fx + fy * fy);
+  if (mu * fz >= nxy) { ox = fx; oy = fy; oz = fz; return; }      // :10-12
+  if (fz < -mu * nxy) { ox = 0.0; oy = 0.0; oz = 0.0; return; }   // :15-17
+  const double ratio = mu * fz / nxy;                              // :20
+  double rx = ratio * fx, ry = ratio * fy, rz = fz;
+  const double z2 = rx * rx + ry * ry + rz * rz;
+  if (z2 > 0.0) {  // Eigen normalize() leaves a zero vector untouched (f_z == 0 quirk)
+    const double nr = sqrt(z2);
+    rx /= nr; ry /= nr; rz /= nr;
+  }
+  const double dot = rx * fx + ry * fy + rz * fz;                  // :23
+  ox = dot * rx; oy = dot * ry; oz = dot * rz;
+}
+
+template <int SLOTS, bool MAT_IN_LDS>
+__global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x;
+  const int inst = blockIdx.x;
+  if (inst >= a.batch) return;
+  const int n = a.n, m = a.m, nc = a.nc, s0 = a.s, N = n + m;
+  const int npack = (N * (N + 1)) / 2;
+
+  double *M = MAT_IN_LDS ? lds : (a.workspace + (long long)blockIdx.x * a.workspace_stride);
+  double *cone_buf = MAT_IN_LDS ? (lds + npack) : lds;  // nc doubles of cross-lane scratch
+
+  const double *Q = a.Q + (size_t)inst * n * n;
+  const double *A = a.A + (size_t)inst * m * n;
+  const double *bq = a.b + (size_t)inst * n;
+  const double *beq = a.b_eq + (size_t)inst * m;
+  const double *mu = a.mu + (size_t)inst * (nc / 3);
+  const double *lbp = a.lb + (size_t)inst * n;
+  const double *ubp = a.ub + (size_t)inst * n;
+  double *xs = a.x + (size_t)inst * n;
+  double *mux_s = a.mu_x + (size_t)inst * n;
+  double *mulc_s = a.mu_lc + (size_t)inst * nc;
+
+  // ---- per-lane vectors (entry i = lane + 64 t) ------------------------------------------
+  double vb[SLOTS], vlb[SLOTS], vub[SLOTS], vtail[SLOTS];  // b, lb, ub over [0,n); b_eq at [n,N)
+  double x[SLOTS], mux[SLOTS], mulc[SLOTS];
+  bool is_cone[SLOTS];
+  bool all_inf = true;
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const int i = lane + kWave * t;
+    vb[t] = (i < n) ? bq[i] : 0.0;
+    vlb[t] = (i < n) ? lbp[i] : -HUGE_VAL;
+    vub[t] = (i < n) ? ubp[i] : HUGE_VAL;
+    vtail[t] = (i >= n && i < N) ? beq[i - n] : 0.0;
+    is_cone[t] = (i >= s0 && i < s0 + nc);
+    if (i < n) all_inf = all_inf && isinf(vlb[t]) && isinf(vub[t]);  // fcc_qp.cpp:132-133
+    if (a.warm_start) {                                            // :136-139
+      x[t] = (i < n) ? xs[i] : 0.0;
+      mux[t] = (i < n) ? mux_s[i] : 0.0;
+      mulc[t] = is_cone[t] ? mulc_s[i - s0] : 0.0;
+    } else {
+      x[t] = 0.0; mux[t] = 0.0; mulc[t] = 0.0;
+    }
+  }
+  const bool equality_constrained = (nc == 0) && __all(all_inf);
+  int flags = equality_constrained ? kFlagEqualityOnly : 0;
+  long long ticks = 0;
+
+  // ---- assemble the packed lower KKT (fcc_qp.cpp:146-150) --------------------------------
+  auto assemble = [&](double rho) {
+    for (int j = 0; j < N; ++j) {
+      const int cj = col_base(j, N);
+      for (int i = j + lane; i < N; i += kWave) {
+        double v;
+        if (i < n) v = Q[(size_t)i * n + j] + ((i == j) ? rho : 0.0);
+        else if (j < n) v = A[(size_t)(i - n) * n + j];
+        else v = 0.0;
+        M[cj + i] = v;
+      }
+    }
+    wave_sync();
+  };
+
+  // ---- presolve (fcc_qp.cpp:159-178): skipped on warm start unless equality-only ---------
+  if (equality_constrained || !a.warm_start) {
+    flags |= kFlagPresolveRan;
+    assemble(0.0);
+    const long long t0 = wall_clock64();
+    const bool bad = ldlt_factor<SLOTS>(M, N, lane);
+    ticks += wall_clock64() - t0;
+    if (bad) flags |= kFlagPresolveNumerical;
+    double r[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const int i = lane + kWave * t;
+      r[t] = (i < n) ? -vb[t] : vtail[t];  // [-b; b_eq]  (:149-150)
+    }
+    ldlt_solve<SLOTS>(M, N, lane, r);
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const int i = lane + kWave * t;
+      x[t] = (i < n) ? r[t] : 0.0;       // x_ = sol.head(n)  (:174)
+    }
+  }
+
+  int n_iter = 0;
+  double x_res_norm = 0.0, lc_res_norm = 0.0;
+
+  // ---- DoADMM (fcc_qp.cpp:57-112) ----------------------------------------------------------
+  if (!equality_constrained) {
+    assemble(a.rho);                                   // :62-64
+    const long long t0 = wall_clock64();
+    const bool bad = ldlt_factor<SLOTS>(M, N, lane);   // :68 (info() unchecked in the reference)
+    ticks += wall_clock64() - t0;
+    if (bad) flags |= kFlagAdmmNumerical;
+
+    double xbar[SLOTS], lcbar[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) { xbar[t] = x[t]; lcbar[t] = x[t]; }  // :74-75
+
+    n_iter = a.max_iter;                               // :78
+    for (int iter = 0; iter < a.max_iter; ++iter) {
+      double r[SLOTS];
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = lane + kWave * t;
+        double q = -a.rho * (xbar[t] - mux[t]);                    // :81
+        if (is_cone[t]) q = -a.rho * (lcbar[t] - mulc[t]);          // :82 overwrites the segment
+        r[t] = (i < n) ? -(vb[t] + q) : vtail[t];                   // :83
+      }
+      ldlt_solve<SLOTS>(M, N, lane, r);                             // :86
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = lane + kWave * t;
+        x[t] = (i < n) ? r[t] : 0.0;                                // :87
+      }
+      // slack update :90-92
+      wave_sync();
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = lane + kWave * t;
+        if (is_cone[t]) cone_buf[i - s0] = x[t] + mulc[t];
+      }
+      wave_sync();
+      double xr_max = -HUGE_VAL, xr_min = HUGE_VAL, lr_max = -HUGE_VAL, lr_min = HUGE_VAL;
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = lane + kWave * t;
+        if (i < n) {
+          const double v = x[t] + mux[t];
+          const double tt = (vub[t] < v) ? vub[t] : v;   // std::min(x, ub)
+          xbar[t] = (tt < vlb[t]) ? vlb[t] : tt;         // std::max(., lb)  constraint_utils.cpp:43
+          const double xr = x[t] - xbar[t];               // :95
+          xr_max = (xr_max < xr) ? xr : xr_max;
+          xr_min = (xr < xr_min) ? xr : xr_min;
+          mux[t] += xr;                                   // :101
+        }
+        if (is_cone[t]) {
+          const int c = (i - s0) / 3, comp = (i - s0) - 3 * c;
+          double ox, oy, oz;
+          project_cone3(cone_buf[3 * c], cone_buf[3 * c + 1], cone_buf[3 * c + 2], mu[c], ox, oy, oz);
+          lcbar[t] = (comp == 0) ? ox : ((comp == 1) ? oy : oz);
+          const double lr = x[t] - lcbar[t];              // :96
+          lr_max = (lr_max < lr) ? lr : lr_max;
+          lr_min = (lr < lr_min) ? lr : lr_min;
+          mulc[t] += lr;                                  // :102
+        }
+      }
+      // :97-98  abs(max(maxCoeff, -minCoeff)); empty contact set defined as 0
+      {
+        const double mx = wave_max(xr_max), mn = wave_min(xr_min);
+        x_res_norm = (n > 0) ? fabs((mx < -mn) ? -mn : mx) : 0.0;
+        const double cmx = wave_max(lr_max), cmn = wave_min(lr_min);
+        lc_res_norm = (nc > 0) ? fabs((cmx < -cmn) ? -cmn : cmx) : 0.0;
+      }
+      if (lc_res_norm < a.eps_fcone && x_res_norm < a.eps_bound) {  // :105-109
+        n_iter = iter;
+        break;
+      }
+    }
+  }
+
+  // ---- epilogue (fcc_qp.cpp:184-186) -------------------------------------------------------
+  double bv = 0.0, cv = 0.0;
+  wave_sync();
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const int i = lane + kWave * t;
+    if (is_cone[t]) cone_buf[i - s0] = x[t];
+  }
+  wave_sync();
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const int i = lane + kWave * t;
+    if (i < n) {
+      const double tt = (vub[t] < x[t]) ? vub[t] : x[t];
+      const double p = (tt < vlb[t]) ? vlb[t] : tt;
+      const double d = x[t] - p;
+      bv += d * d;                                         // constraint_utils.cpp:61-65
+    }
+    if (is_cone[t] && ((i - s0) % 3 == 0)) {
+      const int c = (i - s0) / 3;
+      const double fx = cone_buf[3 * c], fy = cone_buf[3 * c + 1], fz = cone_buf[3 * c + 2];
+      const double v = sqrt(fx * fx + fy * fy) - mu[c] * fz;
+      cv += (0.0 < v) ? v : 0.0;                           // constraint_utils.cpp:48-59
+    }
+  }
+  bv = sqrt(wave_sum(bv));
+  cv = wave_sum(cv);
+
+  // ---- write back state/solution and details ----------------------------------------------
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const int i = lane + kWave * t;
+    if (i < n) { xs[i] = x[t]; mux_s[i] = mux[t]; }
+    if (is_cone[t]) mulc_s[i - s0] = mulc[t];
+  }
+  if (lane == 0) {
+    a.n_iter[inst] = n_iter;
+    a.flags[inst] = flags;
+    a.metrics[0 * (size_t)a.batch + inst] = x_res_norm;
+    a.metrics[1 * (size_t)a.batch + inst] = lc_res_norm;
+    a.metrics[2 * (size_t)a.batch + inst] = bv;
+    a.metrics[3 * (size_t)a.batch + inst] = cv;
+    a.factor_ticks[inst] = ticks;
+  }
+}
+
+inline int slots_for(int N) { return (N + kWave - 1) / kWave; }
+
+template <int SLOTS>
+hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, hipStream_t stream) {
+  dim3 grid(a.batch), block(kWave);
+  if (mat_in_lds) {
+    auto k = generic_kernel<SLOTS, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, stream, a);
+  } else {
+    auto k = generic_kernel<SLOTS, false>;
+    hipLaunchKernelGGL(k, grid, block, lds_bytes, stream, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t generic_lds_bytes(int n, int m, int nc) {
+  const size_t N = (size_t)n + m;
+  return sizeof(double) * (N * (N + 1) / 2 + (size_t)nc + 2);
+}
+
+long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {
+  if (generic_lds_bytes(n, m, nc) <= lds_limit) return 0;
+  const long long N = (long long)n + m;
+  return N * (N + 1) / 2 + 8;
+}
+
+hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream) {
+  const int N = a.n + a.m;
+  if (N > kGenericMaxN) return hipErrorInvalidValue;
+  if (a.batch <= 0) return hipSuccess;
+  const bool in_lds = generic_lds_bytes(a.n, a.m, a.nc) <= lds_limit;
+  const size_t lds = in_lds ? generic_lds_bytes(a.n, a.m, a.nc) : sizeof(double) * ((size_t)a.nc + 2);
+  const int slots = slots_for(N > 0 ? N : 1);
+  switch (slots) {
+    case 1: return launch_slots<1>(a, in_lds, lds, stream);
+    case 2: return launch_slots<2>(a, in_lds, lds, stream);
+    case 3: return launch_slots<3>(a, in_lds, lds, stream);
+    case 4: return launch_slots<4>(a, in_lds, lds, stream);
+    default: return launch_slots<8>(a, in_lds, lds, stream);
+  }
+}
+
+}  // namespace fccqp

@@ -1,0 +1,262 @@
+// pybind_module.cpp -- Python module `fcc_qp_solver`: the reference's Python surface
+// (reference src/main.cpp:19-56: FCCQPDetails, FCCQPOptions, FCCQPSolution, FCCQP with the same
+// attribute / method / keyword names) bound to the MI355X solver, plus FCCQPBatch.
+//
+// numpy in, numpy out.  Like the reference's Eigen::Ref casters, any array convertible to float64
+// is accepted (C- or F-ordered, other dtypes are converted); friction_coeffs may be a list or an
+// array.  Unlike the reference (whose size checks are asserts compiled out of its Release build),
+// shape mismatches raise ValueError and too few friction coefficients raise IndexError.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "fcc_qp.hpp"
+#include "fccqp.h"
+
+namespace py = pybind11;
+
+using fcc_qp::ConstMatrixView;
+using fcc_qp::ConstVectorView;
+using fcc_qp::FCCQP;
+using fcc_qp::FCCQPBatch;
+using fcc_qp::FCCQPBatchSolution;
+using fcc_qp::FCCQPDetails;
+using fcc_qp::FCCQPOptions;
+using fcc_qp::FCCQPSolution;
+
+namespace {
+
+using darray = py::array_t<double, py::array::forcecast>;  // any layout; converts dtype
+using carray = py::array_t<double, py::array::c_style | py::array::forcecast>;
+
+ConstMatrixView mat_view(const darray &a, const char *name) {
+  if (a.ndim() != 2) throw py::value_error(std::string(name) + " must be a 2-D array");
+  return ConstMatrixView(a.data(), (long)a.shape(0), (long)a.shape(1),
+                         (long)(a.strides(0) / (py::ssize_t)sizeof(double)),
+                         (long)(a.strides(1) / (py::ssize_t)sizeof(double)));
+}
+ConstVectorView vec_view(const darray &a, const char *name) {
+  if (a.ndim() == 2 && (a.shape(0) == 1 || a.shape(1) == 1)) {  // column / row vectors, as Eigen accepts
+    const bool col = a.shape(1) == 1;
+    return ConstVectorView(a.data(), (long)(col ? a.shape(0) : a.shape(1)),
+                           (long)(a.strides(col ? 0 : 1) / (py::ssize_t)sizeof(double)));
+  }
+  if (a.ndim() != 1) throw py::value_error(std::string(name) + " must be a 1-D array");
+  return ConstVectorView(a.data(), (long)a.shape(0), (long)(a.strides(0) / (py::ssize_t)sizeof(double)));
+}
+
+py::array_t<double> to_numpy(const std::vector<double> &v) {
+  py::array_t<double> out((py::ssize_t)v.size());
+  std::copy(v.begin(), v.end(), out.mutable_data());
+  return out;
+}
+
+void expect_shape(const carray &a, std::initializer_list<py::ssize_t> shape, const char *name) {
+  bool ok = a.ndim() == (py::ssize_t)shape.size();
+  if (ok) {
+    int k = 0;
+    for (auto d : shape) ok = ok && a.shape(k++) == d;
+  }
+  if (!ok) {
+    std::string s = std::string(name) + " has the wrong shape; expected (";
+    for (auto d : shape) s += std::to_string(d) + ",";
+    s += ")";
+    throw py::value_error(s);
+  }
+}
+
+template <class T>
+py::array_t<T> column(const FCCQPBatchSolution &s, T FCCQPDetails::*member) {
+  py::array_t<T> out((py::ssize_t)s.batch);
+  T *p = out.mutable_data();
+  for (int i = 0; i < s.batch; ++i) p[i] = s.details[(size_t)i].*member;
+  return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(fcc_qp_solver, m) {
+  m.doc() = "Python bindings for the MI355X (HIP/gfx950) batched FCCQP solver for WBC";
+
+  py::register_exception<fcc_qp::FccqpError>(m, "FCCQPError", PyExc_RuntimeError);
+
+  // reference src/main.cpp:22-29 (no constructor; same attribute names)
+  py::class_<FCCQPDetails>(m, "FCCQPDetails")
+      .def_readwrite("n_iter", &FCCQPDetails::n_iter)
+      .def_readwrite("eps_bounds", &FCCQPDetails::admm_residual_bounds)
+      .def_readwrite("eps_friction_cone", &FCCQPDetails::admm_residual_friction_cone)
+      .def_readwrite("bounds_viol", &FCCQPDetails::bounds_viol)
+      .def_readwrite("friction_cone_viol", &FCCQPDetails::friction_cone_viol)
+      .def_readwrite("solve_time", &FCCQPDetails::solve_time)
+      .def_readwrite("factorization_time", &FCCQPDetails::factorization_time)
+      // additions (C++-only in the reference: solve_status, src/fcc_qp.hpp:27)
+      .def_property_readonly("solve_status", [](const FCCQPDetails &d) { return (int)d.solve_status; })
+      .def_readonly("flags", &FCCQPDetails::flags);
+
+  // reference src/main.cpp:31-36
+  py::class_<FCCQPOptions>(m, "FCCQPOptions")
+      .def(py::init<>())
+      .def_readwrite("max_iter", &FCCQPOptions::max_iter)
+      .def_readwrite("rho", &FCCQPOptions::rho)
+      .def_readwrite("eps_fcone", &FCCQPOptions::eps_fcone)
+      .def_readwrite("eps_bound", &FCCQPOptions::eps_bound);
+
+  // reference src/main.cpp:38-40
+  py::class_<FCCQPSolution>(m, "FCCQPSolution")
+      .def_readwrite("details", &FCCQPSolution::details)
+      .def_property(
+          "z", [](const FCCQPSolution &s) { return to_numpy(s.z); },
+          [](FCCQPSolution &s, const carray &v) { s.z.assign(v.data(), v.data() + v.size()); });
+
+  // reference src/main.cpp:42-54
+  py::class_<FCCQP>(m, "FCCQP")
+      .def(py::init<int, int, int, int>(), py::arg("num_vars"), py::arg("num_equality_constraints"),
+           py::arg("nc"), py::arg("lambda_c_start"))
+      .def(py::init<int, int, int, int, int>(), py::arg("num_vars"),
+           py::arg("num_equality_constraints"), py::arg("nc"), py::arg("lambda_c_start"),
+           py::arg("device"))
+      .def("set_rho", &FCCQP::set_rho)
+      .def("set_max_iter", &FCCQP::set_max_iter)
+      .def("set_warm_start", &FCCQP::set_warm_start)
+      .def("set_options", &FCCQP::set_options)
+      .def(
+          "Solve",
+          [](FCCQP &self, const darray &Q, const darray &b, const darray &A_eq, const darray &b_eq,
+             const std::vector<double> &friction_coeffs, const darray &lb, const darray &ub) {
+            ConstMatrixView vQ = mat_view(Q, "Q");
+            ConstMatrixView vA = (A_eq.ndim() == 2) ? mat_view(A_eq, "A_eq")
+                                                    : ConstMatrixView(A_eq.data(), 0, 0, 0, 0);
+            if (A_eq.ndim() != 2 && A_eq.size() != 0) throw py::value_error("A_eq must be a 2-D array");
+            self.Solve(vQ, vec_view(b, "b"), vA, vec_view(b_eq, "b_eq"), friction_coeffs,
+                       vec_view(lb, "lb"), vec_view(ub, "ub"));
+          },
+          py::arg("Q"), py::arg("b"), py::arg("A_eq"), py::arg("b_eq"), py::arg("friction_coeffs"),
+          py::arg("lb"), py::arg("ub"))
+      .def("GetSolution", &FCCQP::GetSolution)
+      .def("contact_vars_start", &FCCQP::contact_vars_start);
+
+  // ---- batched API (new) ---------------------------------------------------------------
+  py::class_<FCCQPBatchSolution>(m, "FCCQPBatchSolution")
+      .def_property_readonly("z",
+                             [](const FCCQPBatchSolution &s) {
+                               py::array_t<double> out({(py::ssize_t)s.batch, (py::ssize_t)s.num_vars});
+                               std::copy(s.z.begin(), s.z.end(), out.mutable_data());
+                               return out;
+                             })
+      .def_property_readonly("n_iter", [](const FCCQPBatchSolution &s) { return column<int>(s, &FCCQPDetails::n_iter); })
+      .def_property_readonly("eps_bounds", [](const FCCQPBatchSolution &s) { return column<double>(s, &FCCQPDetails::admm_residual_bounds); })
+      .def_property_readonly("eps_friction_cone", [](const FCCQPBatchSolution &s) { return column<double>(s, &FCCQPDetails::admm_residual_friction_cone); })
+      .def_property_readonly("bounds_viol", [](const FCCQPBatchSolution &s) { return column<double>(s, &FCCQPDetails::bounds_viol); })
+      .def_property_readonly("friction_cone_viol", [](const FCCQPBatchSolution &s) { return column<double>(s, &FCCQPDetails::friction_cone_viol); })
+      .def_property_readonly("solve_time", [](const FCCQPBatchSolution &s) { return column<double>(s, &FCCQPDetails::solve_time); })
+      .def_property_readonly("factorization_time", [](const FCCQPBatchSolution &s) { return column<double>(s, &FCCQPDetails::factorization_time); })
+      .def_property_readonly("flags", [](const FCCQPBatchSolution &s) { return column<int>(s, &FCCQPDetails::flags); })
+      .def_property_readonly("solve_status",
+                             [](const FCCQPBatchSolution &s) {
+                               py::array_t<int> out((py::ssize_t)s.batch);
+                               for (int i = 0; i < s.batch; ++i) out.mutable_data()[i] = (int)s.details[(size_t)i].solve_status;
+                               return out;
+                             })
+      .def("__len__", [](const FCCQPBatchSolution &s) { return s.batch; })
+      .def("__getitem__", [](const FCCQPBatchSolution &s, int i) {
+        if (i < 0) i += s.batch;
+        if (i < 0 || i >= s.batch) throw py::index_error();
+        FCCQPSolution one;
+        one.details = s.details[(size_t)i];
+        one.z.assign(s.z.begin() + (size_t)i * s.num_vars, s.z.begin() + (size_t)(i + 1) * s.num_vars);
+        return one;
+      });
+
+  py::class_<FCCQPBatch>(m, "FCCQPBatch")
+      .def(py::init<int, int, int, int, int, int>(), py::arg("num_vars"),
+           py::arg("num_equality_constraints"), py::arg("nc"), py::arg("lambda_c_start"),
+           py::arg("batch"), py::arg("device") = 0)
+      .def("set_rho", &FCCQPBatch::set_rho)
+      .def("set_max_iter", &FCCQPBatch::set_max_iter)
+      .def("set_warm_start", &FCCQPBatch::set_warm_start)
+      .def("set_options", &FCCQPBatch::set_options)
+      .def("set_kernel", &FCCQPBatch::set_kernel)
+      .def("kernel_in_use", &FCCQPBatch::kernel_in_use)
+      .def_property_readonly("batch", &FCCQPBatch::batch)
+      .def(
+          "Solve",
+          [](FCCQPBatch &self, const carray &Q, const carray &b, const carray &A_eq, const carray &b_eq,
+             const carray &friction_coeffs, const carray &lb, const carray &ub) {
+            const py::ssize_t B = self.batch(), n = self.num_vars(), mm = self.num_equality_constraints();
+            const py::ssize_t nf = self.nc() / 3;
+            expect_shape(Q, {B, n, n}, "Q");
+            expect_shape(b, {B, n}, "b");
+            if (mm > 0) expect_shape(A_eq, {B, mm, n}, "A_eq");
+            if (mm > 0) expect_shape(b_eq, {B, mm}, "b_eq");
+            expect_shape(lb, {B, n}, "lb");
+            expect_shape(ub, {B, n}, "ub");
+            // friction_coeffs: [B, k] or a single [k] row shared by every instance, k >= nc/3
+            std::vector<double> tiled;
+            const double *fp = friction_coeffs.data();
+            int k = 0;
+            if (friction_coeffs.ndim() == 2 && friction_coeffs.shape(0) == B) {
+              k = (int)friction_coeffs.shape(1);
+            } else if (friction_coeffs.ndim() == 1) {
+              k = (int)friction_coeffs.shape(0);
+              tiled.resize((size_t)B * (size_t)k);
+              for (py::ssize_t i = 0; i < B; ++i)
+                std::copy(fp, fp + k, tiled.begin() + (size_t)i * (size_t)k);
+              fp = tiled.data();
+            } else {
+              throw py::value_error("friction_coeffs must have shape (batch, k) or (k,)");
+            }
+            if (k < nf) throw py::index_error("friction_coeffs has fewer than nc/3 entries per instance");
+            py::gil_scoped_release release;
+            self.Solve(Q.data(), b.data(), A_eq.data(), b_eq.data(), fp, k, lb.data(), ub.data());
+          },
+          py::arg("Q"), py::arg("b"), py::arg("A_eq"), py::arg("b_eq"), py::arg("friction_coeffs"),
+          py::arg("lb"), py::arg("ub"))
+      .def(
+          "SolveDevice",
+          [](FCCQPBatch &self, std::uintptr_t Q, std::uintptr_t b, std::uintptr_t A_eq, std::uintptr_t b_eq,
+             std::uintptr_t friction_coeffs, std::uintptr_t lb, std::uintptr_t ub, std::uintptr_t stream) {
+            self.SolveDevice(reinterpret_cast<const double *>(Q), reinterpret_cast<const double *>(b),
+                             reinterpret_cast<const double *>(A_eq), reinterpret_cast<const double *>(b_eq),
+                             reinterpret_cast<const double *>(friction_coeffs),
+                             reinterpret_cast<const double *>(lb), reinterpret_cast<const double *>(ub),
+                             reinterpret_cast<void *>(stream));
+          },
+          py::arg("Q"), py::arg("b"), py::arg("A_eq"), py::arg("b_eq"), py::arg("friction_coeffs"),
+          py::arg("lb"), py::arg("ub"), py::arg("stream") = 0,
+          "Asynchronous solve from device pointers (ints, e.g. torch.Tensor.data_ptr()) of "
+          "instance-major float64 arrays resident on the solver's GPU.")
+      .def("Synchronize", &FCCQPBatch::Synchronize, py::call_guard<py::gil_scoped_release>())
+      .def("GetSolution", &FCCQPBatch::GetSolution)
+      .def("LastKernelMilliseconds", &FCCQPBatch::LastKernelMilliseconds)
+      .def("AlgorithmicBytes", &FCCQPBatch::AlgorithmicBytes)
+      .def("device_pointers",
+           [](FCCQPBatch &self) {
+             const double *z = nullptr, *met = nullptr;
+             const int *it = nullptr, *fl = nullptr;
+             const long long *tk = nullptr;
+             int rc = fccqp_get_solution_device(self.handle(), &z, &it, &fl, &met, &tk);
+             if (rc != FCCQP_OK) throw fcc_qp::FccqpError(rc, fccqp_strerror(rc));
+             py::dict d;
+             d["z"] = (std::uintptr_t)z;
+             d["n_iter"] = (std::uintptr_t)it;
+             d["flags"] = (std::uintptr_t)fl;
+             d["metrics"] = (std::uintptr_t)met;
+             d["factor_ticks"] = (std::uintptr_t)tk;
+             return d;
+           },
+           "Device addresses of the last solve's results (see include/fccqp.h).");
+
+  m.def("device_count", &fccqp_device_count);
+  m.attr("KERNEL_AUTO") = (int)FCCQP_KERNEL_AUTO;
+  m.attr("KERNEL_GENERIC") = (int)FCCQP_KERNEL_GENERIC;
+  m.attr("KERNEL_FUSED") = (int)FCCQP_KERNEL_FUSED;
+  m.attr("FLAG_PRESOLVE_RAN") = (int)FCCQP_FLAG_PRESOLVE_RAN;
+  m.attr("FLAG_PRESOLVE_NUMERICAL") = (int)FCCQP_FLAG_PRESOLVE_NUMERICAL;
+  m.attr("FLAG_ADMM_NUMERICAL") = (int)FCCQP_FLAG_ADMM_NUMERICAL;
+  m.attr("FLAG_EQUALITY_ONLY") = (int)FCCQP_FLAG_EQUALITY_ONLY;
+}

@@ -1,0 +1,167 @@
+/*
+ * fccqp.h -- C ABI of the MI355X (gfx950) batched friction-cone QP solver.
+ *
+ * This is the drop-in boundary for the hot path of Brian-Acosta/fcc_qp:
+ *     FCCQP::Solve  -> FCCQP::DoADMM          (reference src/fcc_qp.cpp:57-191)
+ *     projections / violation metrics          (reference src/constraint_utils.cpp:5-65)
+ * The reference has no C ABI of its own (its boundary is the C++ class fcc_qp::FCCQP,
+ * src/fcc_qp.hpp:54-172, exported to Python by src/main.cpp:19-56).  The functions below are
+ * what that class binds to when its Eigen body is replaced by the HIP path: the C++ class
+ * fcc_qp::FCCQP / fcc_qp::FCCQPBatch in fcc_qp_amd/csrc/fcc_qp.hpp is implemented purely on top
+ * of this header, and INTEGRATION.md shows the same binding for the reference's own sources.
+ *
+ * Data layout ("instance-major"): the batch index is the slowest dimension and every instance
+ * is one contiguous row-major (C order) block --
+ *     Q[batch][n][n]   b[batch][n]   A_eq[batch][m][n]   b_eq[batch][m]
+ *     friction_coeffs[batch][nc/3]   lb[batch][n]   ub[batch][n]   z[batch][n]
+ * so the 64 lanes of the wavefront that owns an instance read consecutive 8-byte words.
+ * Only the lower triangle of Q is read (Q[i][j], i >= j), as Eigen's LDLT does in the
+ * reference (src/fcc_qp.cpp:68,161 with the default UpLo = Lower).
+ *
+ * All arithmetic is IEEE fp64.  There is no CPU fallback: every entry point that needs the GPU
+ * returns FCCQP_ERR_NO_DEVICE when none is present.
+ *
+ * Threading: a solver handle is stateful (warm-start state, workspace) and not re-entrant, like
+ * the reference class; distinct handles are independent (one per GPU / per thread).
+ */
+#ifndef FCCQP_H
+#define FCCQP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCCQP_VERSION_MAJOR 0
+#define FCCQP_VERSION_MINOR 1
+
+/* ---- status codes (the reference reports nothing: void returns + asserts compiled out in
+ * Release, src/fcc_qp.cpp:29-33,122-130; shape errors here are a documented superset) ------- */
+enum {
+  FCCQP_OK = 0,
+  FCCQP_ERR_INVALID_ARG = 1,     /* NULL pointer, bad enum value, bad handle                    */
+  FCCQP_ERR_SHAPE = 2,           /* sizes violate fcc_qp.cpp:29-33 (nc%3, lambda_c_start+nc<=n) */
+  FCCQP_ERR_NO_DEVICE = 3,       /* no HIP device / device index out of range                   */
+  FCCQP_ERR_HIP = 4,             /* a HIP runtime call failed; see fccqp_last_error()           */
+  FCCQP_ERR_ALLOC = 5,
+  FCCQP_ERR_FRICTION_COEFFS = 6, /* fewer than nc/3 coefficients: the reference throws
+                                    std::out_of_range from .at() (constraint_utils.cpp:32,55)   */
+  FCCQP_ERR_NOT_SOLVED = 7,      /* get_solution before any solve                               */
+  FCCQP_ERR_UNSUPPORTED = 8      /* shape too large for the device workspace                    */
+};
+
+/* reference: enum FCCQPSolveStatus, src/fcc_qp.hpp:14-17 */
+enum { FCCQP_STATUS_SUCCESS = 0, FCCQP_STATUS_MAX_ITERATIONS = 1 };
+
+/* per-instance flag bits (diagnostics beyond the reference struct) */
+enum {
+  FCCQP_FLAG_PRESOLVE_RAN = 1,          /* presolve branch of fcc_qp.cpp:159 executed            */
+  FCCQP_FLAG_PRESOLVE_NUMERICAL = 2,    /* presolve LDL^T met a zero / non-finite pivot: where
+                                           the reference would switch to its COD fallback
+                                           (fcc_qp.cpp:164-166); z is then NOT comparable       */
+  FCCQP_FLAG_ADMM_NUMERICAL = 4,        /* ADMM LDL^T met a zero / non-finite pivot              */
+  FCCQP_FLAG_EQUALITY_ONLY = 8          /* nc == 0 and all bounds infinite: no ADMM (:132-133)   */
+};
+
+/* kernel selection */
+enum {
+  FCCQP_KERNEL_AUTO = 0,     /* specialised kernel when the shape has one, else generic          */
+  FCCQP_KERNEL_GENERIC = 1,  /* any shape: LDS/global-resident KKT, triangular solves per iter   */
+  FCCQP_KERNEL_FUSED = 2     /* shape-specialised register-resident kernel                       */
+};
+
+/* reference: struct FCCQPOptions, src/fcc_qp.hpp:30-35 (same defaults) */
+typedef struct fccqp_options {
+  int max_iter;      /* 1000 */
+  double rho;        /* 1e-6 */
+  double eps_fcone;  /* 1e-3 */
+  double eps_bound;  /* 1e-6 */
+} fccqp_options;
+
+/* reference: struct FCCQPDetails, src/fcc_qp.hpp:19-28, one per instance */
+typedef struct fccqp_details {
+  int n_iter;
+  double admm_residual_bounds;         /* python: eps_bounds        (main.cpp:24) */
+  double admm_residual_friction_cone;  /* python: eps_friction_cone (main.cpp:25) */
+  double solve_time;          /* seconds: host wall clock of the solve call that produced it     */
+  double factorization_time;  /* seconds: device time this instance spent in its factorisations  */
+  double bounds_viol;
+  double friction_cone_viol;
+  int solve_status;           /* FCCQP_STATUS_*  (n_iter == max_iter ? MAX_ITERATIONS : SUCCESS) */
+  int flags;                  /* FCCQP_FLAG_* */
+} fccqp_details;
+
+typedef struct fccqp_solver fccqp_solver;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int fccqp_version(void);                 /* major*100 + minor */
+const char *fccqp_strerror(int code);
+int fccqp_device_count(void);            /* number of HIP devices visible (0 if none)           */
+
+/* ---- life cycle   (replaces FCCQP::FCCQP, reference src/fcc_qp.cpp:24-55) ------------------ */
+/* `batch` independent instances of one shape, resident on HIP device `device`.
+ * The reference constructor is batch = 1. */
+int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_c_start,
+                 int batch, int device, fccqp_solver **out);
+int fccqp_destroy(fccqp_solver *s);
+const char *fccqp_last_error(const fccqp_solver *s);
+
+/* ---- options      (replaces set_rho/set_max_iter/set_options/set_warm_start,
+ *                    reference src/fcc_qp.hpp:75-91) ---------------------------------------- */
+int fccqp_default_options(fccqp_options *opt);
+int fccqp_set_options(fccqp_solver *s, const fccqp_options *opt);
+int fccqp_get_options(const fccqp_solver *s, fccqp_options *opt);
+int fccqp_set_warm_start(fccqp_solver *s, int warm_start);
+int fccqp_set_kernel(fccqp_solver *s, int kernel);   /* FCCQP_KERNEL_* */
+int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use);
+int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
+                    int *lambda_c_start, int *batch, int *device);
+
+/* ---- solve        (replaces FCCQP::Solve, reference src/fcc_qp.cpp:114-191) ---------------- */
+/* Host-pointer form: borrows the seven host arrays for the duration of the call (as the
+ * reference borrows its Eigen::Ref arguments), copies them to the device, solves the whole
+ * batch and waits.  n_friction = coefficients supplied PER INSTANCE (must be >= nc/3; the row
+ * stride of friction_coeffs is n_friction). */
+int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
+                const double *b_eq, const double *friction_coeffs, int n_friction,
+                const double *lb, const double *ub);
+
+/* Device-pointer form: the seven arrays are already resident in HBM on the solver's device
+ * (instance-major, friction stride nc/3).  Enqueues on `stream` (a hipStream_t, or NULL for the
+ * solver's own stream) and returns without waiting. */
+int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, const double *dA_eq,
+                       const double *db_eq, const double *dfriction, const double *dlb,
+                       const double *dub, void *stream);
+int fccqp_synchronize(fccqp_solver *s);
+
+/* ---- results      (replaces FCCQP::GetSolution, reference src/fcc_qp.cpp:194-207) ----------- */
+/* Copies z[batch][n] and details[batch] to the host (either may be NULL).  Waits for the solve. */
+int fccqp_get_solution(fccqp_solver *s, double *z, fccqp_details *details);
+
+/* Device-resident results of the last solve (valid until the next solve / destroy):
+ * z[batch][n] (f64); n_iter[batch], flags[batch] (i32);
+ * metrics[4][batch] (f64) = residual_bounds, residual_cone, bounds_viol, cone_viol;
+ * factor_ticks[batch] (i64, 100 MHz device clock ticks).  Any out pointer may be NULL. */
+int fccqp_get_solution_device(fccqp_solver *s, const double **z, const int **n_iter,
+                              const int **flags, const double **metrics,
+                              const long long **factor_ticks);
+
+/* ---- warm-start state (x, mu_x, mu_lambda_c of reference src/fcc_qp.hpp:145-150) ------------ */
+int fccqp_get_state(fccqp_solver *s, double *x, double *mu_x, double *mu_lambda_c);
+int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x,
+                    const double *mu_lambda_c);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* Milliseconds the last solve's kernel(s) took on the device (hipEvent pair on the launch
+ * stream); waits for the solve. */
+int fccqp_last_kernel_ms(fccqp_solver *s, float *ms);
+/* Compulsory HBM bytes one solve of the whole batch moves:
+ * 8 * batch * (n^2 + m*n + 4n + m + nc/3), plus the warm-start state when warm. */
+int fccqp_algorithmic_bytes(const fccqp_solver *s, long long *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCCQP_H */

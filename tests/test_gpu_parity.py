@@ -1,0 +1,190 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/fccqp.h), against the
+CPU oracle on identical seeded inputs.  Run on the MI355X box:  pytest tests -m gpu
+Reference behaviour under test: FCCQP::Solve / DoADMM (/root/reference/src/fcc_qp.cpp:57-191)."""
+import numpy as np
+import pytest
+
+from fcc_qp_amd import problems as P
+from tests import capi as CAPI
+from tests.helpers import Z_TOL, Z_TOL_TIGHT, assert_parity, oracle_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [CAPI.KERNEL_GENERIC, CAPI.KERNEL_AUTO]
+
+
+def gpu_solve(shape, options, batch, kernel=CAPI.KERNEL_AUTO, warm=False, solver=None):
+    s = solver or CAPI.Solver(*shape.ctor_args, batch=batch.batch)
+    s.set_options(**options)
+    s.set_kernel(kernel)
+    s.set_warm_start(warm)
+    s.solve_ok(*batch.arrays())
+    z, d = s.solution()
+    it = np.array([x.n_iter for x in d])
+    return z, it, d, s
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("wl", ["W-sat", "W-easy", "W-mix"])
+def test_walking_workloads_match_oracle(oracle, wl, kernel):
+    B = P.workload(wl, 96, P.WALKING)
+    z_ref, it_ref, det_ref = oracle_batch(oracle, P.WALKING.ctor_args, P.HARNESS_OPTIONS, B)
+    z, it, d, _ = gpu_solve(P.WALKING, P.HARNESS_OPTIONS, B, kernel)
+    err, dn = assert_parity(z, it, z_ref, it_ref, tol=Z_TOL_TIGHT, what=f"{wl}/k{kernel}")
+    # details agree too
+    for i in range(B.batch):
+        assert d[i].solve_status == det_ref[i].solve_status
+        assert abs(d[i].bounds_viol - det_ref[i].bounds_viol) <= 1e-6 * (1 + abs(det_ref[i].bounds_viol))
+        assert abs(d[i].friction_cone_viol - det_ref[i].friction_cone_viol) <= 1e-6 * (1 + abs(det_ref[i].friction_cone_viol))
+        assert d[i].flags & CAPI.FLAG_PRESOLVE_RAN
+        assert not (d[i].flags & (CAPI.FLAG_PRESOLVE_NUMERICAL | CAPI.FLAG_ADMM_NUMERICAL))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("options", [
+    dict(max_iter=1000, rho=1e-2, eps_fcone=1e-6, eps_bound=1e-6),   # converges: intermediate n_iter
+    dict(max_iter=200, rho=1e-3, eps_fcone=1e-4, eps_bound=1e-4),
+    P.PAPER_OPTIONS,
+    dict(max_iter=1, rho=5e-5, eps_fcone=1e-6, eps_bound=1e-6),
+    dict(max_iter=1000, rho=1e-6, eps_fcone=1e-3, eps_bound=1e-6),   # reference defaults (fcc_qp.hpp:30-35)
+])
+def test_option_sets_match_oracle(oracle, options, kernel):
+    B = P.workload("W-mix", 48, P.WALKING)
+    z_ref, it_ref, _ = oracle_batch(oracle, P.WALKING.ctor_args, options, B)
+    z, it, _, _ = gpu_solve(P.WALKING, options, B, kernel)
+    assert_parity(z, it, z_ref, it_ref, tol=Z_TOL, what=str(options))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_large_shape_matches_oracle(oracle, kernel):
+    B = P.workload("W-mix", 24, P.LARGE)
+    z_ref, it_ref, _ = oracle_batch(oracle, P.LARGE.ctor_args, P.HARNESS_OPTIONS, B)
+    z, it, _, _ = gpu_solve(P.LARGE, P.HARNESS_OPTIONS, B, kernel)
+    assert_parity(z, it, z_ref, it_ref, tol=Z_TOL, what="large")
+
+
+def _random_qp(rng, n, m, nc, s, finite_bounds=True):
+    G = rng.normal(size=(n, n))
+    Q = G @ G.T + 0.5 * np.eye(n)
+    A = rng.normal(size=(m, n))
+    lb = np.full(n, -np.inf); ub = np.full(n, np.inf)
+    if finite_bounds:
+        idx = [i for i in range(n) if not (s <= i < s + nc)][: max(1, n // 4)]
+        lb[idx] = -rng.uniform(0.05, 0.5, len(idx)); ub[idx] = rng.uniform(0.05, 0.5, len(idx))
+    return dict(Q=Q, b=rng.normal(size=n), A_eq=A, b_eq=rng.normal(size=m),
+                friction_coeffs=rng.uniform(0.3, 1.0, nc // 3), lb=lb, ub=ub)
+
+
+@pytest.mark.parametrize("dims", [(3, 0, 3, 0), (7, 2, 3, 4), (12, 5, 6, 3), (20, 20, 0, 0), (33, 9, 9, 24),
+                                  (64, 0, 12, 10), (65, 63, 3, 0), (100, 40, 30, 50), (130, 70, 24, 100)])
+def test_odd_shapes_match_oracle(oracle, dims):
+    """Ragged sizes around the wavefront width (64) and the register-slot boundaries (128, 192)."""
+    n, m, nc, s = dims
+    rng = np.random.default_rng(sum(dims))
+    opts = dict(max_iter=60, rho=0.1, eps_fcone=1e-7, eps_bound=1e-7)
+    B = P.stack([_random_qp(rng, n, m, nc, s) for _ in range(6)])
+    z_ref, it_ref, _, _ = oracle.solve_batch(dims, opts, *B.arrays(), nthreads=2)
+    s_ = CAPI.Solver(n, m, nc, s, batch=6); s_.set_options(**opts)
+    s_.solve_ok(*B.arrays())
+    z, d = s_.solution()
+    assert_parity(z, [x.n_iter for x in d], z_ref, it_ref, tol=Z_TOL, what=str(dims))
+
+
+def test_equality_only_closed_form(oracle):
+    """nc == 0 and infinite bounds: no ADMM, n_iter == 0, x = K^-1 [-b; b_eq] (fcc_qp.cpp:132-133,159-178)."""
+    rng = np.random.default_rng(5)
+    n, m = 30, 11
+    qps = [_random_qp(rng, n, m, 0, 0, finite_bounds=False) for _ in range(5)]
+    B = P.stack(qps)
+    s = CAPI.Solver(n, m, 0, 0, batch=5); s.set_options(100, 1e-3, 1e-6, 1e-6)
+    s.solve_ok(*B.arrays())
+    z, d = s.solution()
+    for i, q in enumerate(qps):
+        K = np.block([[q["Q"], q["A_eq"].T], [q["A_eq"], np.zeros((m, m))]])
+        x = np.linalg.solve(K, np.r_[-q["b"], q["b_eq"]])[:n]
+        assert np.allclose(z[i], x, rtol=1e-9, atol=1e-9)
+        assert d[i].n_iter == 0 and d[i].solve_status == 0
+        assert d[i].flags & CAPI.FLAG_EQUALITY_ONLY
+        assert d[i].admm_residual_bounds == 0.0 and d[i].admm_residual_friction_cone == 0.0
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_warm_start_chain_matches_oracle(oracle, kernel):
+    """The reference harness loop (fcc_qp_test.py:86-89): set_warm_start(i > 0) over a sequence;
+    here 16 independent chains advance in lock-step as one batch."""
+    chains, steps = 16, 6
+    seqs = [P.gait_sequence(steps, P.WALKING, seed0=7000 + 50 * c) for c in range(chains)]
+    opts = P.PAPER_OPTIONS
+    solver = CAPI.Solver(*P.WALKING.ctor_args, batch=chains)
+    solver.set_options(**opts); solver.set_kernel(kernel)
+    orcs = []
+    for c in range(chains):
+        o = oracle.OracleFCCQP(*P.WALKING.ctor_args)
+        op = oracle.FCCQPOptions(); op.__dict__.update(opts); o.set_options(op)
+        orcs.append(o)
+    for t in range(steps):
+        B = P.stack([seqs[c][t] for c in range(chains)])
+        solver.set_warm_start(t > 0)
+        solver.solve_ok(*B.arrays())
+        z, d = solver.solution()
+        z_ref = np.zeros_like(z); it_ref = []
+        for c, o in enumerate(orcs):
+            o.set_warm_start(t > 0)
+            o.Solve(**seqs[c][t]); sol = o.GetSolution()
+            z_ref[c] = sol.z; it_ref.append(sol.details.n_iter)
+        assert_parity(z, [x.n_iter for x in d], z_ref, it_ref, tol=Z_TOL, what=f"chain step {t}")
+        if t > 0:
+            assert all(not (x.flags & CAPI.FLAG_PRESOLVE_RAN) for x in d)   # presolve skipped (cpp:159)
+    x, mux, mulc = solver.state()
+    for c, o in enumerate(orcs):
+        xo, mo, lo = o.get_state()
+        assert np.max(np.abs(mux[c] - mo)) <= 1e-6 * (1 + np.max(np.abs(mo)))
+        assert np.max(np.abs(mulc[c] - lo)) <= 1e-6 * (1 + np.max(np.abs(lo)))
+
+
+def test_friction_coeffs_too_short_is_an_error():
+    B = P.workload("W-easy", 2, P.WALKING)
+    s = CAPI.Solver(*P.WALKING.ctor_args, batch=2)
+    arrs = list(B.arrays()); arrs[4] = arrs[4][:, :3]     # 3 < nc/3 = 4
+    assert s.solve(*arrs) == CAPI.ERR_FRICTION
+
+
+def test_extra_friction_coeffs_are_ignored(oracle):
+    """The reference reads only the first nc/3 coefficients (constraint_utils.cpp:30-33)."""
+    B = P.workload("W-sat", 4, P.WALKING)
+    arrs = list(B.arrays())
+    arrs[4] = np.concatenate([arrs[4], np.full((4, 2), 123.0)], axis=1)
+    s = CAPI.Solver(*P.WALKING.ctor_args, batch=4); s.set_options(**P.HARNESS_OPTIONS)
+    s.solve_ok(*arrs); z1, _ = s.solution()
+    s.solve_ok(*B.arrays()); z2, _ = s.solution()
+    assert np.array_equal(z1, z2)
+
+
+def test_batch_4096_properties(oracle):
+    """BASELINE size (batch = 4096, walking shape) through size-independent properties:
+    (1) permutation equivariance, bit for bit; (2) replicated instances in distinct buffers give
+    bit-identical results; (3) equality constraints hold at the exit; (4) a sample of instances
+    matches the oracle."""
+    nb = 4096
+    B = P.workload("W-mix", nb, P.WALKING, distinct=256)
+    s = CAPI.Solver(*P.WALKING.ctor_args, batch=nb); s.set_options(**P.HARNESS_OPTIONS)
+    s.solve_ok(*B.arrays()); z, d = s.solution()
+    it = np.array([x.n_iter for x in d])
+    assert np.all(np.isfinite(z))
+    # (2) tiles of 256 distinct instances
+    for r in range(1, nb // 256):
+        assert np.array_equal(z[:256], z[256 * r:256 * (r + 1)])
+        assert np.array_equal(it[:256], it[256 * r:256 * (r + 1)])
+    # (1) permutation
+    perm = np.random.default_rng(0).permutation(nb)
+    Bp = P.Batch(*(a[perm] for a in B.arrays()))
+    s.solve_ok(*Bp.arrays()); zp, dp = s.solution()
+    assert np.array_equal(zp, z[perm])
+    assert np.array_equal(np.array([x.n_iter for x in dp]), it[perm])
+    # (3) A x = b_eq at exit (x is the KKT primal iterate, fcc_qp.cpp:87)
+    r = np.einsum("bij,bj->bi", B.A_eq, z) - B.b_eq
+    assert np.max(np.abs(r)) <= 1e-7 * (1 + np.max(np.abs(B.b_eq)))
+    # (4) sample vs oracle
+    sl = B.slice(0, 256)
+    z_ref, it_ref, _ = oracle_batch(oracle, P.WALKING.ctor_args, P.HARNESS_OPTIONS, sl)
+    assert_parity(z[:256], it[:256], z_ref, it_ref, tol=Z_TOL_TIGHT, what="4096 sample")

@@ -48,18 +48,35 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
 
 
+#: shapes with a fused kernel (must match the instantiations in csrc/fccqp_fused.hip)
+FUSED_SHAPES = [(60, 38), (12, 5)]
+
+
+def generate_p3(force: bool = False) -> List[str]:
+    """Run csrc/gen_p3.py: phase P3 of the fused kernel as straight-line code, one file per shape."""
+    gen = os.path.join(CSRC, "gen_p3.py")
+    outs = []
+    for n, m in FUSED_SHAPES:
+        inc = os.path.join(CSRC, f"fccqp_p3_{n}_{m}.inc")
+        if force or _newer(inc, [gen]):
+            _run([sys.executable, gen, str(n), str(m), inc])
+        outs.append(inc)
+    return outs
+
+
 def build_lib(force: bool = False) -> str:
+    incs = generate_p3(force)
     srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip")]
-    deps = srcs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
-                   os.path.join(ROOT, "include", "fccqp.h")]
+    deps = srcs + incs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
+                          os.path.join(ROOT, "include", "fccqp.h")]
     if force or _newer(LIB, deps):
         objs = []
         for src in srcs:
             obj = os.path.splitext(src)[0] + ".o"
             if force or _newer(obj, deps):
                 _run([hipcc(), "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-                      "-fgpu-rdc" if False else "-fno-gpu-rdc", "-ffp-contract=off",
-                      "-Wall", "-Wno-unused-function", "-c", src, "-o", obj])
+                      "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+                      "-Wno-unused-variable", "-c", src, "-o", obj])
             objs.append(obj)
         _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
     return LIB

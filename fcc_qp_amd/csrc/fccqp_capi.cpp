@@ -38,6 +38,7 @@ struct fccqp_solver {
   double *dx = nullptr, *dmux = nullptr, *dmulc = nullptr, *dmetrics = nullptr, *dwork = nullptr;
   int *dniter = nullptr, *dflags = nullptr;
   long long *dticks = nullptr;
+  long long *dphase = nullptr;  // [8][batch], allocated on demand
   long long work_stride = 0;
   std::string err;
 };
@@ -105,12 +106,13 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   a.Q = dQ; a.b = db; a.A = dA; a.b_eq = dbeq; a.mu = dmu; a.lb = dlb; a.ub = dub;
   a.x = s->dx; a.mu_x = s->dmux; a.mu_lc = s->dmulc;
   a.n_iter = s->dniter; a.flags = s->dflags; a.metrics = s->dmetrics;
-  a.factor_ticks = s->dticks; a.workspace = s->dwork; a.workspace_stride = s->work_stride;
+  a.factor_ticks = s->dticks; a.phase_ticks = s->dphase; a.workspace = s->dwork; a.workspace_stride = s->work_stride;
 
   const bool want_fused = s->kernel_request != FCCQP_KERNEL_GENERIC;
-  const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s);
+  const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s) && fccqp::fused_pointers_ok(a);
   if (s->kernel_request == FCCQP_KERNEL_FUSED && !can_fuse)
-    return fail(s, FCCQP_ERR_UNSUPPORTED, "no fused kernel is compiled for this shape");
+    return fail(s, FCCQP_ERR_UNSUPPORTED,
+                "no fused kernel for this shape, or Q / A_eq not 16-byte aligned");
   HIP_TRY(s, hipEventRecord(s->ev0, stream));
   hipError_t e;
   if (want_fused && can_fuse) {
@@ -226,7 +228,7 @@ int fccqp_destroy(fccqp_solver *s) {
   DeviceGuard g(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, s->dx, s->dmux, s->dmulc,
-                  s->dmetrics, s->dwork, s->dniter, s->dflags, s->dticks};
+                  s->dmetrics, s->dwork, s->dniter, s->dflags, s->dticks, s->dphase};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -415,6 +417,29 @@ int fccqp_last_kernel_ms(fccqp_solver *s, float *ms) {
   DeviceGuard g(s->device);
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return FCCQP_OK;
+}
+
+int fccqp_phase_seconds(fccqp_solver *s, double out[8]) {
+  if (!s || !out) return FCCQP_ERR_INVALID_ARG;
+  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  DeviceGuard g(s->device);
+  const size_t B = (size_t)s->batch;
+  if (!s->dphase) {
+    if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+    HIP_TRY(s, dmalloc(&s->dphase, 8 * B));
+    HIP_TRY(s, hipMemset(s->dphase, 0, sizeof(long long) * 8 * B));
+    return FCCQP_OK;
+  }
+  if (!s->solved) return FCCQP_OK;
+  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  std::vector<long long> h(8 * B);
+  HIP_TRY(s, hipMemcpy(h.data(), s->dphase, sizeof(long long) * 8 * B, hipMemcpyDeviceToHost));
+  for (int p = 0; p < 8; ++p) {
+    double acc = 0.0;
+    for (size_t i = 0; i < B; ++i) acc += (double)h[(size_t)p * B + i];
+    out[p] = 1e-8 * acc / (double)B;
+  }
   return FCCQP_OK;
 }
 

@@ -23,6 +23,7 @@ struct KernelArgs {
   int *flags;             // [batch]  FCCQP_FLAG_*
   double *metrics;        // [4][batch] residual_bounds, residual_cone, bounds_viol, cone_viol
   long long *factor_ticks;  // [batch] 100 MHz ticks spent factorising
+  long long *phase_ticks;  // optional [8][batch]: 100 MHz ticks per phase (fused kernel), or null
   double *workspace;      // generic kernel, large shapes: per-block packed KKT in global memory
   long long workspace_stride;  // doubles per block
 };
@@ -44,6 +45,7 @@ hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t str
 
 // ---- fused shape-specialised kernels (fccqp_fused.hip) ---------------------------------------
 bool fused_supported(int n, int m, int nc, int s);
+bool fused_pointers_ok(const KernelArgs &a);  // 16-byte alignment of Q and A_eq
 hipError_t launch_fused(const KernelArgs &a, hipStream_t stream);
 
 }  // namespace fccqp

@@ -157,6 +157,11 @@ int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x,
 /* Milliseconds the last solve's kernel(s) took on the device (hipEvent pair on the launch
  * stream); waits for the solve. */
 int fccqp_last_kernel_ms(fccqp_solver *s, float *ms);
+/* Mean device time (seconds) the instances of the last solve spent per phase, fused kernel only:
+ * out[0] KKT assembly, [1] factorisations, [2] presolve triangular solve, [3] P3 (G and x_c),
+ * [4] ADMM iterations, [5] whole kernel per instance; [6],[7] reserved (0).  Profiling aid: the
+ * first call enables the stamps for subsequent solves and returns zeros. */
+int fccqp_phase_seconds(fccqp_solver *s, double out[8]);
 /* Compulsory HBM bytes one solve of the whole batch moves:
  * 8 * batch * (n^2 + m*n + 4n + m + nc/3), plus the warm-start state when warm. */
 int fccqp_algorithmic_bytes(const fccqp_solver *s, long long *bytes);

@@ -62,6 +62,7 @@ def lib():
         L.fccqp_set_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.fccqp_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.fccqp_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        L.fccqp_phase_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -135,6 +136,11 @@ class Solver:
         ms = C.c_float()
         self._ck(self.L.fccqp_last_kernel_ms(self.h, C.byref(ms)), "last_kernel_ms")
         return ms.value
+
+    def phase_seconds(self):
+        out = (C.c_double * 8)()
+        self._ck(self.L.fccqp_phase_seconds(self.h, out), "phase_seconds")
+        return list(out)
 
     def algorithmic_bytes(self):
         b = C.c_longlong()

@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- QP solves/sec at batch = 4096, walking-log shape, on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: every rank solves its own 4096 independent
+cold-start QPs (workload W-sat of fcc_qp_amd/problems.py: FCCQP(60, 38, 12, 38) instances that run
+the full max_iter = 100 ADMM iterations under the reference harness options, fcc_qp_test.py:78-83)
+with one launch of the fused HIP kernel through the C ABI (fccqp_solve_device, include/fccqp.h).
+Inputs are resident in HBM before the timed region starts; z and the details stay on the device.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+The batch shards embarrassingly: one process per GPU, no data-path collective (torch.distributed
+over RCCL is used only for the barriers and the MAX over ranks of the elapsed time).  Scaling is
+weak: every GPU gets its own 4096 instances, `value` counts all of them.
+
+Rank 0 prints ONE JSON line with the driver's fields plus
+  "roofline":     algorithmic HBM bytes per launch / mean kernel time (HIP events on the launch
+                  stream) against the 8 TB/s HBM3E peak -- the contract figure; this path is
+                  latency/LDS-bound, not bandwidth-bound, so the fraction is small;
+  "cpu_baseline": the CPU restatement of the reference algorithm (oracle/, kind "port": the
+                  reference itself needs Eigen, which is not in the image) on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+BATCH_PER_GPU = 4096
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU (metric: 4096)")
+    ap.add_argument("--workload", default="W-sat", choices=["W-sat", "W-mix", "W-easy"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fused"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(shape, options, batch_obj, log):
+    """Oracle (CPU restatement of the reference algorithm) on the host cores: a bounded sample of the
+    same workload.  Returns the cpu_baseline JSON object.  This is the checker being TIMED as the
+    baseline, never part of the product path."""
+    from oracle import oracle as O
+
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU box's CPU share is 16 cores; FCCQP_BENCH_CPU_THREADS overrides
+    cores = max(1, min(avail, int(os.environ.get("FCCQP_BENCH_CPU_THREADS", "16"))))
+    # -O3 -march=native build of the same C file (the parity build keeps -ffp-contract=off)
+    fast = os.path.join(ROOT, "oracle", "libfccqp_oracle_native.so")
+    lib = None
+    try:
+        src = os.path.join(ROOT, "oracle", "fccqp_oracle.c")
+        if (not os.path.exists(fast)) or os.path.getmtime(fast) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-DNDEBUG", "-fPIC", "-std=c99",
+                                   "-D_POSIX_C_SOURCE=200809L", "-shared", "-o", fast, src, "-lm", "-lpthread"])
+        lib = ctypes.CDLL(fast)
+        lib.fccqp_oracle_solve_batch.restype = ctypes.c_double
+        lib.fccqp_oracle_solve_batch.argtypes = O.lib().fccqp_oracle_solve_batch.argtypes
+    except Exception as exc:  # fall back to the parity build of the oracle
+        log(f"[bench] native oracle build failed ({exc}); timing the -O3 parity build")
+        lib = O.lib()
+
+    import numpy as np
+
+    n, m, nc, s = shape.ctor_args
+    sample = min(batch_obj.batch, 4096)
+    sl = batch_obj.slice(0, sample)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in sl.arrays()]
+    ptr = [a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) for a in arrs]
+    z = np.zeros((sample, n))
+    it = np.zeros(sample, dtype=np.int32)
+
+    def run(nthreads, count):
+        return lib.fccqp_oracle_solve_batch(
+            n, m, nc, s, int(options["max_iter"]), float(options["rho"]), float(options["eps_fcone"]),
+            float(options["eps_bound"]), count, *ptr, z.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+            it.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), None, nthreads)
+
+    # one thread: comparable with the reference's single-threaded use (fccqp.pdf Fig. 1)
+    one = min(sample, 256)
+    t1 = min(run(1, one) for _ in range(2))
+    # all cores: one solver instance per thread over a static partition of the sample
+    tn = min(run(cores, sample) for _ in range(3))
+    return {
+        "value": sample / tn, "unit": "solves/s", "cores": cores, "kind": "port",
+        "sample": f"first {sample} instances of the same batch, best of 3 passes, {cores} threads "
+                  f"(one oracle solver per thread, gcc -O3 -march=native)",
+        "single_thread_value": one / t1, "single_thread_us_per_solve": 1e6 * t1 / one,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import fcc_qp_amd as F
+    from fcc_qp_amd import problems as P
+
+    shape, options = P.WALKING, dict(P.HARNESS_OPTIONS)
+    nb = args.batch
+    t0 = time.time()
+    batch = P.workload(args.workload, nb, shape, seed0=1000 + rank * nb)   # instance i: seed 1000 + i
+    log(f"[bench] generated {nb} '{args.workload}' instances per rank in {time.time() - t0:.1f} s")
+
+    solver = F.FCCQPBatch(*shape.ctor_args, nb, local_rank)
+    o = F.FCCQPOptions()
+    o.max_iter, o.rho, o.eps_fcone, o.eps_bound = (options["max_iter"], options["rho"],
+                                                   options["eps_fcone"], options["eps_bound"])
+    solver.set_options(o)
+    solver.set_warm_start(False)
+    solver.set_kernel({"auto": F.KERNEL_AUTO, "generic": F.KERNEL_GENERIC, "fused": F.KERNEL_FUSED}[args.kernel])
+    tens = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in batch.arrays()]   # resident in HBM
+    torch.cuda.synchronize()
+
+    def step():
+        F.solve_tensors(solver, *tens)          # one launch on torch's current stream
+
+    # ---- parity gate: a sample against the CPU oracle --------------------
+    step()
+    torch.cuda.synchronize()
+    sol = solver.GetSolution()
+    n_iter = np.asarray(sol.n_iter)
+    parity = None
+    if rank == 0 and not args.no_parity_gate:
+        from oracle import oracle as O
+        k = min(256, nb)
+        z_ref, it_ref, _, _ = O.solve_batch(shape.ctor_args, options, *batch.slice(0, k).arrays(), nthreads=8)
+        err = np.max(np.abs(sol.z[:k] - z_ref), axis=1) / (1.0 + np.max(np.abs(z_ref), axis=1))
+        dn = np.abs(n_iter[:k].astype(np.int64) - it_ref.astype(np.int64))
+        parity = {"sample": k, "max_rel_err": float(err.max()), "max_dn_iter": int(dn.max())}
+        if not (err.max() <= 1e-6 and dn.max() <= 1):
+            raise SystemExit(f"parity gate failed: {parity}")
+        log(f"[bench] parity vs oracle on {k} instances: {parity}")
+
+    # ---- timed region ------------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]        # HIP events on the launch stream
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total = nb * world * args.steps
+        value = total / elapsed
+        mean_ms = float(np.mean(kernel_ms))
+        alg_bytes = solver.AlgorithmicBytes()                  # 8 * batch * (n^2 + mn + 4n + m + nc/3)
+        achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tr_path):
+            try:
+                tr = json.load(open(tr_path))
+                if tr.get("batch") == nb and tr.get("workload") == args.workload and tr.get("kernel") == solver.kernel_in_use():
+                    traffic = tr.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "QP solves/sec at batch=4096, walking-log shape",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: FCCQP(60,38,12,38) walking-shape OSC QPs, cold start, "
+                            f"rho=5e-5 eps=1e-6/1e-6 max_iter=100 (fcc_qp_test.py:78-83)",
+                "batch_per_gpu": nb, "global_batch": nb * world, "parallelism": f"batch-sharded x{world}, no collective",
+                "kernel": {1: "generic", 2: "fused"}[solver.kernel_in_use()],
+                "n_iter_mean": float(n_iter.mean()), "n_iter_at_max_frac": float(np.mean(n_iter == options["max_iter"])),
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms_mean": mean_ms, "kernel_ms_min": float(np.min(kernel_ms)),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "parity": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(shape, options, batch, log)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,7 +144,7 @@ class FCCQPBatch {
   // host pointers; n_friction = friction coefficients per instance (>= nc/3)
   void Solve(const double *Q, const double *b, const double *A_eq, const double *b_eq,
              const double *friction_coeffs, int n_friction, const double *lb, const double *ub);
-  // device pointers, asynchronous on `stream` (hipStream_t or nullptr)
+  // device pointers, asynchronous on `stream` (hipStream_t; nullptr = HIP's default stream)
   void SolveDevice(const double *dQ, const double *db, const double *dA_eq, const double *db_eq,
                    const double *dfriction, const double *dlb, const double *dub, void *stream);
   void Synchronize();

@@ -325,7 +325,7 @@ int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, cons
     return fail(s, FCCQP_ERR_INVALID_ARG, "null device pointer");
   DeviceGuard g(s->device);
   if (!g.ok) return fail(s, FCCQP_ERR_NO_DEVICE, "hipSetDevice failed");
-  hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : s->stream;
+  hipStream_t st = (stream == FCCQP_STREAM_OWN) ? s->stream : reinterpret_cast<hipStream_t>(stream);
   s->last_solve_wall = 0.0;
   return enqueue(s, dQ, db, dA_eq, db_eq, dfriction, dlb, dub, st);
 }

@@ -129,8 +129,11 @@ int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double 
                 const double *lb, const double *ub);
 
 /* Device-pointer form: the seven arrays are already resident in HBM on the solver's device
- * (instance-major, friction stride nc/3).  Enqueues on `stream` (a hipStream_t, or NULL for the
- * solver's own stream) and returns without waiting. */
+ * (instance-major, friction stride nc/3).  Enqueues on `stream` and returns without waiting.
+ * `stream` is a hipStream_t: NULL is HIP's default (null) stream, as everywhere in HIP;
+ * FCCQP_STREAM_OWN selects the solver's private non-blocking stream.  The fused kernel fetches
+ * Q and A_eq 16 bytes at a time: if either is not 16-byte aligned the generic kernel is used. */
+#define FCCQP_STREAM_OWN ((void *)(intptr_t)-1)
 int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, const double *dA_eq,
                        const double *db_eq, const double *dfriction, const double *dlb,
                        const double *dub, void *stream);

@@ -1,0 +1,51 @@
+"""Turns the rocprofv3 output of tools/profile_gpu.sh (gpurun_out/prof_<tag>/) into the committed
+evidence under profiles/:  <tag>_kernel_stats.csv (the --kernel-trace --stats summary),
+<tag>_pmc_summary.json (FETCH_SIZE / WRITE_SIZE per launch) and hbm_traffic.json (what bench.py
+reports as roofline.traffic).
+
+HBM bytes per launch follow MI355X_MICROARCH.md section "HBM": FETCH_SIZE and WRITE_SIZE are in KiB,
+collected in separate --pmc passes; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide
+coalesced 16 B/lane read stream (which is how Q and A_eq are read), so it is doubled; WRITE_SIZE is
+taken as is.   usage: python tools/parse_profile.py <tag> [batch] [workload]
+"""
+import csv, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+workload = sys.argv[3] if len(sys.argv) > 3 else "W-sat"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+def per_launch(path, counter):
+    vals = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and "fccqp" in r["Kernel_Name"]:
+            vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
+
+fetch, nf = per_launch(os.path.join(src, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
+write, nw = per_launch(os.path.join(src, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE")
+stats = list(csv.DictReader(open(os.path.join(dst, f"{tag}_kernel_stats.csv"))))
+summary = {"tag": tag, "batch": batch, "workload": workload, "kernels": {}}
+for k in fetch:
+    f_kib, w_kib = fetch[k], write.get(k, 0.0)
+    hbm = 2.0 * f_kib * 1024.0 + w_kib * 1024.0
+    avg_ns = next((float(s["AverageNs"]) for s in stats if s["Name"] == k), None)
+    summary["kernels"][k] = {
+        "FETCH_SIZE_KiB_per_launch": f_kib, "WRITE_SIZE_KiB_per_launch": w_kib,
+        "launches_sampled": [nf[k], nw.get(k, 0)],
+        "hbm_bytes_per_launch_corrected": hbm,
+        "correction": "2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B for 16 B/lane streams) + WRITE_SIZE",
+        "trace_average_ns": avg_ns,
+    }
+json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
+main = max(summary["kernels"].items(), key=lambda kv: kv[1]["hbm_bytes_per_launch_corrected"])
+kernel_id = 2 if "fused" in main[0] else 1
+json.dump({"batch": batch, "workload": workload, "kernel": kernel_id, "tag": tag,
+           "hbm_bytes_per_launch": main[1]["hbm_bytes_per_launch_corrected"]},
+          open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))

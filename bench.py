@@ -127,11 +127,12 @@ def main():
 
     import fcc_qp_amd as F
     from fcc_qp_amd import problems as P
+    from fcc_qp_amd import sharding as S
 
     shape, options = P.WALKING, dict(P.HARNESS_OPTIONS)
     nb = args.batch
     t0 = time.time()
-    batch = P.workload(args.workload, nb, shape, seed0=1000 + rank * nb)   # instance i: seed 1000 + i
+    batch = P.workload(args.workload, nb, shape, seed0=S.rank_seed0(rank, nb))   # instance i: seed 1000 + i
     log(f"[bench] generated {nb} '{args.workload}' instances per rank in {time.time() - t0:.1f} s")
 
     solver = F.FCCQPBatch(*shape.ctor_args, nb, local_rank)
@@ -169,8 +170,7 @@ def main():
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    S.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for e0, e1 in ev:
@@ -178,20 +178,16 @@ def main():
         step()
         e1.record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    S.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]        # HIP events on the launch stream
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = S.max_over_ranks(elapsed, dev)          # the slowest rank defines the step time
+    solved = S.sum_over_ranks(float(nb * args.steps), dev)
 
     if rank == 0:
-        total = nb * world * args.steps
-        value = total / elapsed
+        value = solved / elapsed
         mean_ms = float(np.mean(kernel_ms))
         alg_bytes = solver.AlgorithmicBytes()                  # 8 * batch * (n^2 + mn + 4n + m + nc/3)
         achieved = alg_bytes / (mean_ms * 1e-3) / 1e9

@@ -1,0 +1,117 @@
+"""The reference's Python call sequence (/root/reference/fcc_qp_test.py:77-89) and the new batched
+API, through the pybind11 module, on the GPU."""
+import numpy as np
+import pytest
+
+from fcc_qp_amd import problems as P
+from tests.helpers import Z_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def harness_options(F):
+    o = F.FCCQPOptions()
+    o.rho = 5e-5; o.eps_fcone = 1e-6; o.eps_bound = 1e-6; o.max_iter = 100     # fcc_qp_test.py:78-83
+    return o
+
+
+def test_reference_harness_loop_matches_oracle(oracle):
+    """solver.set_warm_start(i > 0); solver.Solve(...); solver.GetSolution()  over a sequence."""
+    from fcc_qp import FCCQP, FCCQPOptions, FCCQPSolution      # the reference's import line (fcc_qp_test.py:6)
+    import fcc_qp_amd as F
+    qps = P.gait_sequence(8, P.WALKING, seed0=9100)
+    solver = FCCQP(60, 38, 12, 38)
+    solver.set_options(harness_options(F))
+    ref = oracle.OracleFCCQP(60, 38, 12, 38)
+    op = oracle.FCCQPOptions(); op.__dict__.update(P.HARNESS_OPTIONS); ref.set_options(op)
+    for i, qp in enumerate(qps):
+        solver.set_warm_start(i > 0); ref.set_warm_start(i > 0)
+        solver.Solve(qp["Q"], qp["b"], qp["A_eq"], qp["b_eq"], qp["friction_coeffs"], qp["lb"], qp["ub"])
+        result = solver.GetSolution()
+        assert isinstance(result, FCCQPSolution)
+        ref.Solve(**qp); r = ref.GetSolution()
+        assert np.max(np.abs(result.z - r.z)) <= Z_TOL * (1 + np.max(np.abs(r.z)))
+        d = result.details
+        assert abs(d.n_iter - r.details.n_iter) <= 1
+        assert abs(d.bounds_viol - r.details.bounds_viol) <= 1e-6 * (1 + r.details.bounds_viol)
+        assert abs(d.friction_cone_viol - r.details.friction_cone_viol) <= 1e-6 * (1 + r.details.friction_cone_viol)
+        assert d.solve_time > 0 and d.factorization_time > 0 and d.factorization_time < d.solve_time
+
+
+def test_keyword_arguments_lists_and_foreign_layouts(oracle):
+    """Eigen::Ref casters of the reference accept F-ordered / non-f64 arrays and lists."""
+    import fcc_qp_amd as F
+    qp = P.osc_qp(1000, P.WALKING)
+    s = F.FCCQP(num_vars=60, num_equality_constraints=38, nc=12, lambda_c_start=38)
+    s.set_options(harness_options(F))
+    s.Solve(Q=qp["Q"], b=qp["b"], A_eq=qp["A_eq"], b_eq=qp["b_eq"], friction_coeffs=qp["friction_coeffs"],
+            lb=qp["lb"], ub=qp["ub"])
+    z0 = s.GetSolution().z
+    s.Solve(np.asfortranarray(qp["Q"]), list(qp["b"]), np.asfortranarray(qp["A_eq"]), qp["b_eq"].reshape(-1, 1),
+            list(qp["friction_coeffs"]), qp["lb"], qp["ub"][::1])
+    assert np.array_equal(s.GetSolution().z, z0)
+    s.set_rho(5e-5); s.set_max_iter(100)
+    s.Solve(**{k: qp[k] for k in ("Q", "b", "A_eq", "b_eq", "friction_coeffs", "lb", "ub")})
+    assert np.array_equal(s.GetSolution().z, z0)
+
+
+def test_error_behaviour():
+    import fcc_qp_amd as F
+    qp = P.osc_qp(1000, P.WALKING)
+    s = F.FCCQP(60, 38, 12, 38)
+    with pytest.raises(ValueError):
+        s.Solve(qp["Q"][:59, :59], qp["b"], qp["A_eq"], qp["b_eq"], qp["friction_coeffs"], qp["lb"], qp["ub"])
+    with pytest.raises(ValueError):
+        s.Solve(qp["Q"], qp["b"], qp["A_eq"][:37], qp["b_eq"], qp["friction_coeffs"], qp["lb"], qp["ub"])
+    with pytest.raises(IndexError):          # std::out_of_range from .at() in the reference
+        s.Solve(qp["Q"], qp["b"], qp["A_eq"], qp["b_eq"], qp["friction_coeffs"][:3], qp["lb"], qp["ub"])
+    with pytest.raises(ValueError):
+        F.FCCQP(60, 38, 13, 38)
+    z = s.GetSolution()                      # before any successful Solve: zeros, like the reference
+    assert np.array_equal(z.z, np.zeros(60)) and z.details.n_iter == 0
+
+
+def test_batch_api_matches_oracle_and_single_instance_api(oracle):
+    import fcc_qp_amd as F
+    nb = 40
+    B = P.workload("W-mix", nb, P.WALKING)
+    bs = F.FCCQPBatch(60, 38, 12, 38, nb)
+    bs.set_options(harness_options(F))
+    bs.Solve(*B.arrays())
+    sol = bs.GetSolution()
+    z_ref, it_ref, _, _ = oracle.solve_batch(P.WALKING.ctor_args, P.HARNESS_OPTIONS, *B.arrays(), nthreads=4)
+    err = np.max(np.abs(sol.z - z_ref), axis=1) / (1 + np.max(np.abs(z_ref), axis=1))
+    assert err.max() <= Z_TOL and np.abs(sol.n_iter - it_ref).max() <= 1
+    assert len(sol) == nb and sol.z.shape == (nb, 60)
+    one = F.FCCQP(60, 38, 12, 38); one.set_options(harness_options(F))
+    qp = B.instance(7)
+    one.Solve(qp["Q"], qp["b"], qp["A_eq"], qp["b_eq"], qp["friction_coeffs"], qp["lb"], qp["ub"])
+    assert np.array_equal(one.GetSolution().z, sol[7].z)          # same kernel, same bits
+    assert sol[7].details.n_iter == sol.n_iter[7]
+    # a single friction row is shared by every instance
+    bs.Solve(B.Q, B.b, B.A_eq, B.b_eq, B.friction_coeffs[0], B.lb, B.ub)
+    assert np.array_equal(bs.GetSolution().z, sol.z)
+    with pytest.raises(ValueError):
+        bs.Solve(B.Q[:-1], B.b, B.A_eq, B.b_eq, B.friction_coeffs, B.lb, B.ub)
+    with pytest.raises(IndexError):
+        bs.Solve(B.Q, B.b, B.A_eq, B.b_eq, B.friction_coeffs[:, :3], B.lb, B.ub)
+
+
+def test_torch_tensors_resident_in_hbm_give_the_same_bits():
+    import torch
+    import fcc_qp_amd as F
+    nb = 64
+    B = P.workload("W-sat", nb, P.WALKING)
+    bs = F.FCCQPBatch(60, 38, 12, 38, nb); bs.set_options(harness_options(F))
+    bs.Solve(*B.arrays()); host = bs.GetSolution()
+    tens = [torch.from_numpy(a).cuda() for a in B.arrays()]
+    F.solve_tensors(bs, *tens)
+    torch.cuda.synchronize()
+    dev = bs.GetSolution()
+    assert np.array_equal(dev.z, host.z) and np.array_equal(dev.n_iter, host.n_iter)
+    assert bs.LastKernelMilliseconds() > 0
+    assert bs.AlgorithmicBytes() == 8 * nb * (60 * 60 + 38 * 60 + 4 * 60 + 38 + 4)
+    with pytest.raises(ValueError):
+        F.solve_tensors(bs, *[t.float() for t in tens])
+    ptrs = bs.device_pointers()
+    assert ptrs["z"] != 0 and ptrs["n_iter"] != 0

@@ -13,6 +13,15 @@ import os as _os
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 
+# PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever
+# copy is loaded first serves the whole process; torch refuses to see any GPU when the system copy
+# got there first.  So if torch is installed, let it load its runtime before our library does --
+# libfccqp_hip.so then binds to that same runtime and device pointers / streams are shared.
+try:  # pragma: no cover - depends on the environment
+    import torch as _torch  # noqa: F401
+except Exception:  # torch is optional plumbing, not a dependency of the solver
+    _torch = None
+
 try:
     from .fcc_qp_solver import (  # noqa: F401
         FCCQP, FCCQPBatch, FCCQPBatchSolution, FCCQPDetails, FCCQPError, FCCQPOptions, FCCQPSolution,

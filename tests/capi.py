@@ -42,6 +42,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        try:
+            import torch  # noqa: F401  (load torch's bundled HIP runtime first: see fcc_qp_amd/__init__.py)
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         L.fccqp_strerror.restype = C.c_char_p
         L.fccqp_last_error.restype = C.c_char_p

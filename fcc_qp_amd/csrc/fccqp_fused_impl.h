@@ -107,21 +107,34 @@ __device__ __forceinline__ double wave_max(double v) {
   return bcast_lane(v, 63);
 }
 
-// reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25
+// reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25.
+// Same three branches and the same f_z == 0 quirk; the side-of-cone branch evaluates
+// (r.f / r.r) r instead of normalising r first ((r/|r|).f (r/|r|), :22-23): identical in exact
+// arithmetic, one division instead of three plus a square root (fp64 div/sqrt are ~15-instruction
+// sequences that every lane of the wave executes), a few ulp apart in floating point.
 __device__ __forceinline__ void project_cone3(double fx, double fy, double fz, double mu,
                                               double &ox, double &oy, double &oz) {
   const double nxy = sqrt(fx * fx + fy * fy);
-  if (mu * fz >= nxy) { ox = fx; oy = fy; oz = fz; return; }      // :10-12
-  if (fz < -mu * nxy) { ox = 0.0; oy = 0.0; oz = 0.0; return; }   // :15-17
-  const double ratio = mu * fz / nxy;                              // :20
-  double rx = ratio * fx, ry = ratio * fy, rz = fz;
+  const bool inside = mu * fz >= nxy;        // :10-12
+  const bool polar = fz < -mu * nxy;         // :15-17
+  const double ratio = mu * fz / nxy;        // :20
+  const double rx = ratio * fx, ry = ratio * fy, rz = fz;
   const double z2 = rx * rx + ry * ry + rz * rz;
-  if (z2 > 0.0) {  // Eigen normalize(): zero vector untouched (the f_z == 0 quirk)
-    const double nr = sqrt(z2);
-    rx /= nr; ry /= nr; rz /= nr;
-  }
-  const double dot = rx * fx + ry * fy + rz * fz;                  // :23
-  ox = dot * rx; oy = dot * ry; oz = dot * rz;
+  const double dot = rx * fx + ry * fy + rz * fz;
+  const double sc = (z2 > 0.0) ? dot / z2 : 0.0;   // Eigen normalize() leaves a zero ray untouched -> 0
+  ox = inside ? fx : (polar ? 0.0 : sc * rx);
+  oy = inside ? fy : (polar ? 0.0 : sc * ry);
+  oz = inside ? fz : (polar ? 0.0 : sc * rz);
+}
+
+// 1/d by v_rcp_f64 + two Newton steps: <= 1 ulp from the correctly rounded quotient, a third of the
+// dependent-instruction chain of an IEEE division (the pivot reciprocal sits on the critical path
+// of every factorisation step).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
 }
 
 // ---- compile-time shape description ------------------------------------------------------------
@@ -138,6 +151,8 @@ struct Shape {
     return j * N - (j * (j - 1)) / 2 + ((N % 2 == 0) ? (j + 1) / 2 : j / 2);
   }
   static constexpr int cbase(int j) { return cstart(j) - j; }
+  // cbase(j + 1) - cbase(j): lets loops walk the columns with one scalar add
+  static constexpr int cstep(int j) { return N - j - 1 + (((j & 1) == (N & 1)) ? 1 : 0); }
   static constexpr int kMat = (cstart(N) + 1) & ~1;
   static constexpr int kNp = (N + 1) & ~1;
   // LDS carve (doubles): matrix | dvec[kNp] | vbuf[max(kNp, 64)]
@@ -157,88 +172,137 @@ struct P3;
 
 // Left-looking panel LDL^T, in place in LDS.  On return M holds L below the diagonal, the
 // diagonal slots hold 1/d (0 where |d| <= DBL_MIN: Eigen's LDLT::solve rule) and dvec holds d.
-// Returns true if a pivot was exactly zero or not finite (where Eigen's info() can fail).
-template <class SH>
-__device__ __forceinline__ bool factor_lds(lds_f64 *M, lds_f64 *dvec, const int lane) {
+// Returns true if a pivot was zero or not finite (where Eigen's info() can fail).
+//
+// Written for instruction count: with one wave per SIMD every instruction -- FMA, readlane,
+// cndmask, scalar address arithmetic alike -- takes a 4-cycle issue slot, so the panel code is
+// compiled twice (USE0: rows < 64 take part / only rows >= 64 do) instead of branching inside,
+// columns are addressed by a running offset, loads are unmasked (rows above the diagonal pick
+// up garbage that is never stored) and the panel is written back once at the end.
+template <class SH, bool USE0>
+__device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const int lane, const int c0) {
   constexpr int N = SH::N, P = kPanel;
-  bool bad_any = false;
   const int row0 = lane, row1 = kWave + lane;
-  const bool has1 = row1 < N;
-#pragma nounroll
-  for (int c0 = 0; c0 < N; c0 += P) {
-    // rows above the panel take no part: slot 0 is idle once c0 >= 64
-    const bool use0 = c0 < kWave;
-    double T0[P], T1[P];
-    // (a) panel columns into registers (rows above the diagonal of a column read as 0)
+  const int r0c = (row0 < N) ? row0 : N - 1;   // clamped rows: in-bounds reads for idle lanes
+  const int r1c = (row1 < N) ? row1 : N - 1;
+  double T0[P], T1[P];
+  // (a) panel columns into registers
 #pragma unroll
-    for (int jj = 0; jj < P; ++jj) {
-      const int j = c0 + jj;
-      const int cb = SH::cbase(j < N ? j : N - 1);
-      T0[jj] = (use0 && j < N && row0 >= j) ? M[cb + row0] : 0.0;
-      T1[jj] = (has1 && j < N && row1 >= j) ? M[cb + row1] : 0.0;
-    }
-    // (b) contribution of every earlier column q:  T[i][j] -= (L[i][q] d_q) L[j][q]
-#pragma nounroll
-    for (int q = 0; q < c0; ++q) {
-      const int cb = SH::cbase(q);
-      const double dq = dvec[q];
-      const lds_d2 *bc = reinterpret_cast<const lds_d2 *>(M + cb + c0);  // rows c0.. of column q
-      d2 w[P / 2];
+  for (int jj = 0; jj < P; ++jj) {
+    const int j = (c0 + jj < N) ? c0 + jj : N - 1;
+    const int cb = SH::cbase(j);
+    T0[jj] = USE0 ? M[cb + r0c] : 0.0;
+    T1[jj] = M[cb + r1c];
+  }
+  // (b) contribution of every earlier column q:  T[i][j] -= (L[i][q] d_q) L[j][q]
+  // two columns per trip, operands of the next column loaded before the FMAs of the current one
+  // (c0 is a multiple of 16, so q and q+1 are always both < c0)
+  struct Ops { d2 w[P / 2]; double u0, u1, dq; };
+  auto fetch = [&](const int cb, const int q, Ops &o) {
+    const lds_d2 *bc = reinterpret_cast<const lds_d2 *>(M + cb + c0);  // rows c0.. of column q
 #pragma unroll
-      for (int t = 0; t < P / 2; ++t) w[t] = bc[t];  // may run past row N-1 in the last panel: unused
-      const double u1 = has1 ? M[cb + row1] * dq : 0.0;
-      if (use0) {
-        const double u0 = M[cb + row0] * dq;  // rows < c0 compute garbage that is never stored
-#pragma unroll
-        for (int t = 0; t < P / 2; ++t) {
-          T0[2 * t] = fma(-u0, w[t].x, T0[2 * t]);
-          T0[2 * t + 1] = fma(-u0, w[t].y, T0[2 * t + 1]);
-        }
-      }
+    for (int t = 0; t < P / 2; ++t) o.w[t] = bc[t];  // may run past row N-1 in the last panel: unused
+    o.dq = dvec[q];
+    o.u0 = USE0 ? M[cb + r0c] : 0.0;
+    o.u1 = M[cb + r1c];
+  };
+  auto apply = [&](const Ops &o) {
+    const double u1 = o.u1 * o.dq;
+    if constexpr (USE0) {
+      const double u0 = o.u0 * o.dq;
 #pragma unroll
       for (int t = 0; t < P / 2; ++t) {
-        T1[2 * t] = fma(-u1, w[t].x, T1[2 * t]);
-        T1[2 * t + 1] = fma(-u1, w[t].y, T1[2 * t + 1]);
+        T0[2 * t] = fma(-u0, o.w[t].x, T0[2 * t]);
+        T0[2 * t + 1] = fma(-u0, o.w[t].y, T0[2 * t + 1]);
       }
     }
-    // (c) factorise the panel itself, column by column
 #pragma unroll
-    for (int k = 0; k < P; ++k) {
-      const int j = c0 + k;
-      if (j < N) {
-        const int src = j & (kWave - 1);
-        const double d = (j < kWave) ? bcast_lane(T0[k], src) : bcast_lane(T1[k], src);
-        const bool bad = !(fabs(d) > 0.0) || !(fabs(d) <= DBL_MAX);
-        bad_any |= bad;
-        const double rinv = 1.0 / d;
-        const double lsc = bad ? 1.0 : rinv;  // Eigen scales the column only by a non-zero pivot
-        const int cb = SH::cbase(j);
-        const double a0 = T0[k], a1 = T1[k];
-        const double l0 = a0 * lsc, l1 = a1 * lsc;
-        if (use0 && row0 > j && row0 < N) M[cb + row0] = l0;  // row0 < N matters only when N < 64
-        if (has1 && row1 > j) M[cb + row1] = l1;
-        if (lane == 0) {
-          dvec[j] = d;
-          M[cb + j] = (fabs(d) > DBL_MIN) ? rinv : 0.0;
-        }
-        lds_fence();
-        // rank-1 update of the panel columns to the right:  T[i][jj] -= a_i * l_{c0+jj, j}
-        const lds_d2 *bc = reinterpret_cast<const lds_d2 *>(M + cb + c0);
-#pragma unroll
-        for (int t = (k + 1) / 2; t < P / 2; ++t) {
-          const d2 w = bc[t];
-          if (2 * t > k) {
-            if (use0) T0[2 * t] = fma(-a0, w.x, T0[2 * t]);
-            T1[2 * t] = fma(-a1, w.x, T1[2 * t]);
-          }
-          if (use0) T0[2 * t + 1] = fma(-a0, w.y, T0[2 * t + 1]);
-          T1[2 * t + 1] = fma(-a1, w.y, T1[2 * t + 1]);
-        }
-      }
+    for (int t = 0; t < P / 2; ++t) {
+      T1[2 * t] = fma(-u1, o.w[t].x, T1[2 * t]);
+      T1[2 * t + 1] = fma(-u1, o.w[t].y, T1[2 * t + 1]);
     }
-    lds_fence();
+  };
+  if (c0 > 0) {
+    Ops oa, ob;
+    int cb = SH::cbase(0);
+    fetch(cb, 0, oa);
+#pragma nounroll
+    for (int q = 0; q < c0; q += 2) {
+      cb += SH::cstep(q);
+      fetch(cb, q + 1, ob);
+      apply(oa);
+      cb += SH::cstep(q + 1);
+      fetch(cb, (q + 2 < N) ? q + 2 : q + 1, oa);   // one column past the end on the last trip: unused
+      apply(ob);
+    }
   }
+  // (c) factorise the panel itself, column by column.  All 16 panel rows live in one register
+  // slot (64 is a multiple of 16), so the multipliers l_{c0+jj, j} of the in-panel update are
+  // read straight out of the owner lanes (v_readlane) -- no LDS round trip on the critical path.
+  const int lane0 = c0 & (kWave - 1);
+  const int rel = lane - lane0;            // position of this lane's diagonal-block row in the panel
+  bool bad_any = false;
+  double dmine = 1.0, rmine = 0.0;
+#pragma unroll
+  for (int k = 0; k < P; ++k) {
+    const double d = bcast_lane(USE0 ? T0[k] : T1[k], lane0 + k);
+    // zero, infinite or NaN pivot (class mask: sNaN|qNaN|-inf|-0|+0|+inf)
+    bad_any |= __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
+    const double rinv = fast_rcp(d);
+    dmine = (rel == k) ? d : dmine;
+    rmine = (rel == k) ? ((fabs(d) > DBL_MIN) ? rinv : 0.0) : rmine;
+    const double a0 = T0[k], a1 = T1[k];
+    if constexpr (USE0) T0[k] = a0 * rinv;
+    T1[k] = a1 * rinv;
+    const double lsrc = USE0 ? T0[k] : T1[k];
+    // rank-1 update of the panel columns to the right:  T[i][jj] -= a_i * l_{c0+jj, j}
+#pragma unroll
+    for (int jj = k + 1; jj < P; ++jj) {
+      const double ljj = bcast_lane(lsrc, lane0 + jj);
+      if constexpr (USE0) T0[jj] = fma(-a0, ljj, T0[jj]);
+      T1[jj] = fma(-a1, ljj, T1[jj]);
+      // keep both consumers of the scalar next to its v_readlane pair: left alone the scheduler
+      // separates them and every scalar is spilled to a VGPR lane (v_writelane + s_nop) and read back
+      if constexpr (USE0) asm volatile("" : "+v"(T0[jj]), "+v"(T1[jj]));
+    }
+  }
+  // (d) write the panel back: rows below the diagonal block take all 16 columns ...
+  const int ncol = (N - c0 < P) ? N - c0 : P;   // columns that exist (last panel may be short)
+  if constexpr (USE0) {
+    if (row0 >= c0 + P && row0 < N) {
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        if (k < ncol) M[SH::cbase(c0 + k) + row0] = T0[k];
+    }
+  }
+  if (row1 >= c0 + P && row1 < N) {
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+      if (k < ncol) M[SH::cbase(c0 + k) + row1] = T1[k];
+  }
+  // ... the diagonal block's own rows only what lies strictly below the diagonal, plus d, 1/d
+  {
+    const int rowd = USE0 ? row0 : row1;
+    if (rel >= 0 && rel < ncol) {
+#pragma unroll
+      for (int k = 0; k < P - 1; ++k)
+        if (rel > k) M[SH::cbase(c0 + k) + rowd] = USE0 ? T0[k] : T1[k];
+      dvec[rowd] = dmine;
+      M[SH::cbase(rowd) + rowd] = rmine;
+    }
+  }
+  lds_fence();
   return bad_any;
+}
+
+template <class SH>
+__device__ __forceinline__ bool factor_lds(lds_f64 *M, lds_f64 *dvec, const int lane) {
+  bool bad = false;
+#pragma nounroll
+  for (int c0 = 0; c0 < SH::N && c0 < kWave; c0 += kPanel) bad |= factor_panel<SH, true>(M, dvec, lane, c0);
+#pragma nounroll
+  for (int c0 = kWave; c0 < SH::N; c0 += kPanel) bad |= factor_panel<SH, false>(M, dvec, lane, c0);
+  return bad;
 }
 
 // x := (L D L^T)^-1 x with M as left by factor_lds; x0/x1 are this lane's rows lane / 64+lane.
@@ -248,25 +312,49 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
   const int row0 = lane, row1 = kWave + lane;
   const bool ok0 = row0 < N, ok1 = row1 < N;
   const int cb0 = SH::cbase(ok0 ? row0 : 0), cb1 = SH::cbase(ok1 ? row1 : 0);
-  // forward, unit lower, column oriented
+  // forward, unit lower, column oriented; four columns of L are fetched ahead of the dependent
+  // chain (readlane x_k -> fma), which is all that remains on the critical path
+  constexpr int U = 4;
 #pragma nounroll
-  for (int k = 0; k < N; ++k) {
-    const int src = k & (kWave - 1);
-    const double xk = (k < kWave) ? bcast_lane(x0, src) : bcast_lane(x1, src);
-    const int cb = SH::cbase(k);
-    if (ok0 && row0 > k) x0 = fma(-M[cb + row0], xk, x0);
-    if (ok1 && row1 > k) x1 = fma(-M[cb + row1], xk, x1);
+  for (int k0 = 0; k0 < N; k0 += U) {
+    double a0[U], a1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (k0 + u < N) ? k0 + u : N - 1;
+      const int cb = SH::cbase(k);
+      a0[u] = (ok0 && row0 > k && k0 + u < N) ? M[cb + row0] : 0.0;
+      a1[u] = (ok1 && row1 > k && k0 + u < N) ? M[cb + row1] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (k0 + u < N) ? k0 + u : N - 1;
+      const int src = k & (kWave - 1);
+      const double xk = (k < kWave) ? bcast_lane(x0, src) : bcast_lane(x1, src);
+      x0 = fma(-a0[u], xk, x0);
+      x1 = fma(-a1[u], xk, x1);
+    }
   }
   // the diagonal slot holds 1/d with Eigen's pseudo-inverse rule folded in
   x0 = ok0 ? x0 * M[cb0 + row0] : 0.0;
   x1 = ok1 ? x1 * M[cb1 + row1] : 0.0;
-  // backward with L^T: x_i -= L[k][i] x_k, i < k
+  // backward with L^T: x_i -= L[k][i] x_k, i < k  (row k of L is a gather along this lane's column)
 #pragma nounroll
-  for (int k = N - 1; k > 0; --k) {
-    const int src = k & (kWave - 1);
-    const double xk = (k < kWave) ? bcast_lane(x0, src) : bcast_lane(x1, src);
-    if (ok0 && row0 < k) x0 = fma(-M[cb0 + k], xk, x0);
-    if (ok1 && row1 < k) x1 = fma(-M[cb1 + k], xk, x1);
+  for (int k0 = N - 1; k0 > 0; k0 -= U) {
+    double a0[U], a1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (k0 - u > 0) ? k0 - u : 1;
+      a0[u] = (ok0 && row0 < k && k0 - u > 0) ? M[cb0 + k] : 0.0;
+      a1[u] = (ok1 && row1 < k && k0 - u > 0) ? M[cb1 + k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (k0 - u > 0) ? k0 - u : 1;
+      const int src = k & (kWave - 1);
+      const double xk = (k < kWave) ? bcast_lane(x0, src) : bcast_lane(x1, src);
+      x0 = fma(-a0[u], xk, x0);
+      x1 = fma(-a1[u], xk, x1);
+    }
   }
 }
 
@@ -294,23 +382,22 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   double *mulc_s = a.mu_lc + (size_t)inst * nc;
 
   // ---- vectors, variable layout: lane i <-> variable i (i < n); lane r <-> equality row r ----
+  // The small vectors (b, b_eq, lb, ub, mu, warm-start state) are fetched from global memory at
+  // the point of use instead of being held in registers across the phases: P3 needs nearly the
+  // whole register file, and anything live across it is spilled to scratch and reloaded inside
+  // the ADMM loop.  `fresh()` hides the pointer from CSE so the loads really are redone.
+  auto fresh = [](const double *p) { asm volatile("" : "+s"(p)); return p; };
   const bool isvar = lane < n;
   const bool is_cone = (lane >= s0) && (lane < s0 + nc);
-  const double vb = isvar ? bq[lane] : 0.0;
-  const double vlb = isvar ? lbp[lane] : -HUGE_VAL;
-  const double vub = isvar ? ubp[lane] : HUGE_VAL;
-  const double vbe = (lane < m) ? beq[lane] : 0.0;
   const int cidx = is_cone ? (lane - s0) / 3 : 0;
   const int ccomp = is_cone ? (lane - s0) - 3 * cidx : 0;
-  const double vmu = is_cone ? mup[cidx] : 0.0;
-  double x = 0.0, mux = 0.0, mulc = 0.0;
-  if (a.warm_start) {  // fcc_qp.cpp:136-139
-    x = isvar ? xs[lane] : 0.0;
-    mux = isvar ? mux_s[lane] : 0.0;
-    mulc = is_cone ? mulc_s[lane - s0] : 0.0;
+  double x = 0.0;
+  if (a.warm_start) x = isvar ? xs[lane] : 0.0;  // fcc_qp.cpp:136-139 (duals are fetched at P4)
+  bool equality_constrained = false;             // fcc_qp.cpp:132-133
+  if constexpr (nc == 0) {
+    const double l0 = isvar ? lbp[lane] : -HUGE_VAL, u0 = isvar ? ubp[lane] : HUGE_VAL;
+    equality_constrained = __all(!isvar || (isinf(l0) && isinf(u0)));
   }
-  const bool all_inf = !isvar || (isinf(vlb) && isinf(vub));
-  const bool equality_constrained = (nc == 0) && __all(all_inf);  // fcc_qp.cpp:132-133
   int flags = equality_constrained ? kFlagEqualityOnly : 0;
   long long ticks = 0;
   const bool cold = equality_constrained || !a.warm_start;  // presolve runs (fcc_qp.cpp:159)
@@ -322,21 +409,29 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       if (i >= j) M[SH::cbase(j) + i] = v + ((i == j) ? rho : 0.0);
     };
     if constexpr (n % 2 == 0) {
+      // fully unrolled: the global loads of a whole matrix are in flight together
       const d2 *Q2 = reinterpret_cast<const d2 *>(Q);
-#pragma unroll 4
-      for (int p = lane; p < n * n / 2; p += kWave) {
-        const d2 v = Q2[p];
-        const int e = 2 * p, i = e / n, j = e - i * n;  // n even: a pair never straddles two rows
-        put(i, j, v.x);
-        put(i, j + 1, v.y);
+      constexpr int QP = n * n / 2, AP = m * n / 2;
+#pragma unroll
+      for (int t = 0; t < (QP + kWave - 1) / kWave; ++t) {
+        const int p = lane + kWave * t;
+        if (p < QP) {
+          const d2 v = Q2[p];
+          const int e = 2 * p, i = e / n, j = e - i * n;  // n even: a pair never straddles two rows
+          put(i, j, v.x);
+          put(i, j + 1, v.y);
+        }
       }
       const d2 *A2 = reinterpret_cast<const d2 *>(A);
-#pragma unroll 4
-      for (int p = lane; p < m * n / 2; p += kWave) {
-        const d2 v = A2[p];
-        const int e = 2 * p, r = e / n, j = e - r * n;
-        M[SH::cbase(j) + n + r] = v.x;
-        M[SH::cbase(j + 1) + n + r] = v.y;
+#pragma unroll
+      for (int t = 0; t < (AP + kWave - 1) / kWave; ++t) {
+        const int p = lane + kWave * t;
+        if (p < AP) {
+          const d2 v = A2[p];
+          const int e = 2 * p, r = e / n, j = e - r * n;
+          M[SH::cbase(j) + n + r] = v.x;
+          M[SH::cbase(j + 1) + n + r] = v.y;
+        }
       }
     } else {
       for (int e = lane; e < n * n; e += kWave) { const int i = e / n; put(i, e - i * n, Q[e]); }
@@ -348,17 +443,30 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     lds_fence();
   };
 
+  // [-b; b_eq] (fcc_qp.cpp:149-150) into vbuf[0..N)
+  auto stage_rhs = [&]() {
+    const double *bp = fresh(bq), *ep = fresh(beq);
+    vbuf[lane] = isvar ? -bp[lane] : 0.0;
+    lds_fence();
+    if (lane < m) vbuf[n + lane] = ep[lane];  // n + lane < N <= kVbuf
+    lds_fence();
+  };
+
   int n_iter = 0;
   double x_res_norm = 0.0, lc_res_norm = 0.0;
   // phase stamps (100 MHz): 0 assemble, 1 factor, 2 presolve solve, 3 P3, 4 P4, 5 total
   long long ph_asm = 0, ph_solve = 0, ph_p3 = 0, ph_p4 = 0;
   const long long t_begin = wall_clock64();
 
+  // A cold start needs K twice (presolve on K, ADMM on K + rho I) and the in-place factorisation
+  // destroys it; the second assembly reads Q and A_eq again (L2 / Infinity-Cache hits mostly).
+  // A 39 KB per-lane register copy was tried: the allocator parks it in scratch, which costs more
+  // memory traffic than the re-read.
 #pragma nounroll
   for (int pass = cold ? 0 : 1; pass < 2; ++pass) {
     if (pass == 1 && equality_constrained) break;
     const long long ta = wall_clock64();
-    assemble(pass == 0 ? 0.0 : a.rho);  // P1: K (fcc_qp.cpp:161);  P2: K_rho (fcc_qp.cpp:62-68)
+    assemble(pass == 0 ? 0.0 : a.rho);  // P1: K (fcc_qp.cpp:146-150,161);  P2: K_rho (fcc_qp.cpp:62-64)
     const long long t0 = wall_clock64();
     ph_asm += t0 - ta;
     const bool bad = factor_lds<SH>(M, dvec, lane);
@@ -366,10 +474,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     if (pass == 0) {
       flags |= kFlagPresolveRan | (bad ? kFlagPresolveNumerical : 0);
       // x_ = (K^-1 [-b; b_eq]).head(n)   (fcc_qp.cpp:149-150,174)
-      vbuf[lane] = isvar ? -vb : 0.0;
-      lds_fence();
-      if (lane < m) vbuf[n + lane] = vbe;  // n + lane < N <= kVbuf
-      lds_fence();
+      stage_rhs();
       double r0 = (lane < N) ? vbuf[lane < N ? lane : 0] : 0.0;
       double r1 = (kWave + lane < N) ? vbuf[kWave + lane < N ? kWave + lane : 0] : 0.0;
       lds_fence();
@@ -387,17 +492,23 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     double Mrow[n];
     double xc;
     // right-hand sides: lanes < n take unit vectors, lane n takes [-b; b_eq] out of vbuf
-    vbuf[lane] = isvar ? -vb : 0.0;
-    lds_fence();
-    if (lane < m) vbuf[n + lane] = vbe;
-    lds_fence();
+    stage_rhs();
     const long long t3 = wall_clock64();
     P3<SH>::run(M, vbuf, lane, isvar, a, Mrow, xc);
     const long long t4 = wall_clock64();
     ph_p3 = t4 - t3;
 
     // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------
+    const double vlb = isvar ? fresh(lbp)[lane] : -HUGE_VAL;
+    const double vub = isvar ? fresh(ubp)[lane] : HUGE_VAL;
+    const double vmu = is_cone ? fresh(mup)[cidx] : 0.0;
+    double mux = 0.0, mulc = 0.0;
+    if (a.warm_start) {  // fcc_qp.cpp:136-139
+      mux = isvar ? mux_s[lane] : 0.0;
+      mulc = is_cone ? mulc_s[lane - s0] : 0.0;
+    }
     double xbar = x, lcbar = x;  // :74-75
+    double xr = 0.0, lr = 0.0;
     n_iter = a.max_iter;         // :78
 #pragma nounroll
     for (int iter = 0; iter < a.max_iter; ++iter) {
@@ -405,26 +516,48 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       const double w = is_cone ? (lcbar - mulc) : (xbar - mux);
       vbuf[lane] = isvar ? w : 0.0;
       lds_fence();
-      // x = x_c + (rho G) w   == the KKT solve of :83-87
+      // x = x_c + (rho G) w   == the KKT solve of :83-87.  w comes back from LDS as broadcast pairs,
+      // in chunks of 7 pairs with two chunks in flight (<= 15 loads: the lgkmcnt counter has 4 bits): a lone wave per SIMD has nobody to hide
+      // the ~100-cycle LDS latency behind, so the loads must run ahead of the FMAs (left to itself
+      // the compiler kept 2 loads in flight and stalled on every one).
       double acc0 = xc, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-      const lds_d2 *w2 = reinterpret_cast<const lds_d2 *>(vbuf);
-      static_for<0, (n + 3) / 4>([&](auto qc) {
-        constexpr int j = 4 * decltype(qc)::value;
-        const d2 wa = w2[j / 2];
-        acc0 = fma(Mrow[j], wa.x, acc0);
-        if constexpr (j + 1 < n) acc1 = fma(Mrow[j + 1], wa.y, acc1);
-        if constexpr (j + 2 < n) {
-          const d2 wb = w2[j / 2 + 1];
-          acc2 = fma(Mrow[j + 2], wb.x, acc2);
-          if constexpr (j + 3 < n) acc3 = fma(Mrow[j + 3], wb.y, acc3);
-        }
-      });
+      {
+        const lds_d2 *w2 = reinterpret_cast<const lds_d2 *>(vbuf);
+        constexpr int NP = (n + 1) / 2, CH = 7, NCHUNK = (NP + CH - 1) / CH;
+        d2 wb[2][CH];
+        auto load = [&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          static_for<0, CH>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (c * CH + i < NP) wb[c % 2][i] = w2[c * CH + i];
+          });
+        };
+        load(std::integral_constant<int, 0>{});
+        static_for<0, NCHUNK>([&](auto cc) {
+          constexpr int c = decltype(cc)::value;
+          if constexpr (c + 1 < NCHUNK) load(std::integral_constant<int, c + 1>{});
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<0, CH>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int j = 2 * (c * CH + i);
+            if constexpr (j < n) {
+              if constexpr (i % 2 == 0) acc0 = fma(Mrow[j], wb[c % 2][i].x, acc0);
+              else acc2 = fma(Mrow[j], wb[c % 2][i].x, acc2);
+            }
+            if constexpr (j + 1 < n) {
+              if constexpr (i % 2 == 0) acc1 = fma(Mrow[j + 1], wb[c % 2][i].y, acc1);
+              else acc3 = fma(Mrow[j + 1], wb[c % 2][i].y, acc3);
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
       x = (acc0 + acc1) + (acc2 + acc3);
       lds_fence();
       // slack update :90-92
       if (is_cone) vbuf[lane] = x + mulc;
       lds_fence();
-      double xr = 0.0, lr = 0.0;
+      xr = 0.0; lr = 0.0;
       if (isvar) {
         const double v = x + mux;
         const double tt = min2(v, vub);   // std::min(x(i), ub(i))   constraint_utils.cpp:43
@@ -441,15 +574,28 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
         mulc += lr;                       // :102
       }
       lds_fence();
-      // :97-98  abs(max(maxCoeff, -minCoeff)) == max_i |r_i|; empty contact set defined as 0
-      x_res_norm = wave_max(isvar ? fabs(xr) : 0.0);
-      if constexpr (nc > 0) lc_res_norm = wave_max(is_cone ? fabs(lr) : 0.0);
-      if (lc_res_norm < a.eps_fcone && x_res_norm < a.eps_bound) {  // :105-109
+      // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test
+      // is one ballot instead of two wave reductions; the norms themselves (:97-98) are only
+      // reported, and are reduced once after the loop.  An empty contact set has norm 0.
+      bool ok = !isvar || (fabs(xr) < a.eps_bound);
+      if constexpr (nc > 0) ok = ok && (!is_cone || (fabs(lr) < a.eps_fcone));
+      else ok = ok && (0.0 < a.eps_fcone);
+      if (__all(ok)) {
         n_iter = iter;
         break;
       }
     }
+    if (a.max_iter > 0) {
+      // :97-98  abs(max(maxCoeff, -minCoeff)) == max_i |r_i| of the last iteration executed
+      x_res_norm = wave_max(isvar ? fabs(xr) : 0.0);
+      if constexpr (nc > 0) lc_res_norm = wave_max(is_cone ? fabs(lr) : 0.0);
+    }
+    // duals are part of the warm-start state (fcc_qp.hpp:149-150)
+    if (isvar) mux_s[lane] = mux;
+    if (is_cone) mulc_s[lane - s0] = mulc;
     ph_p4 = wall_clock64() - t4;
+  } else if (!a.warm_start) {
+    if (isvar) mux_s[lane] = 0.0;  // mu_x_.setZero() (fcc_qp.cpp:136-139); nc == 0 here
   }
 
   // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back -----------------------------------------
@@ -458,21 +604,20 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   lds_fence();
   double bv = 0.0, cv = 0.0;
   if (isvar) {
-    const double tt = min2(x, vub);
-    const double p = max2(tt, vlb);
+    const double tt = min2(x, fresh(ubp)[lane]);
+    const double p = max2(tt, fresh(lbp)[lane]);
     const double dd = x - p;
     bv = dd * dd;                                        // constraint_utils.cpp:61-65
   }
   if (is_cone && ccomp == 0) {
     const double fx = vbuf[lane], fy = vbuf[lane + 1], fz = vbuf[lane + 2];
-    const double v = sqrt(fx * fx + fy * fy) - vmu * fz;
+    const double v = sqrt(fx * fx + fy * fy) - fresh(mup)[cidx] * fz;
     cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
   }
   bv = sqrt(wave_sum(bv));
   cv = wave_sum(cv);
 
-  if (isvar) { xs[lane] = x; mux_s[lane] = mux; }
-  if (is_cone) mulc_s[lane - s0] = mulc;
+  if (isvar) xs[lane] = x;
   if (lane == 0) {
     a.n_iter[inst] = n_iter;
     a.flags[inst] = flags;

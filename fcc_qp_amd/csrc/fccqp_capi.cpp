@@ -39,6 +39,11 @@ struct fccqp_solver {
   int *dniter = nullptr, *dflags = nullptr;
   long long *dticks = nullptr;
   long long *dphase = nullptr;  // [8][batch], allocated on demand
+  bool fallback = true;          // device COD fallback for a rank-deficient presolve
+  int *dfb_list = nullptr, *dfb_count = nullptr;
+  double *dcod_ws = nullptr;
+  long long cod_stride = 0;
+  static constexpr int kFallbackBlocks = 64;
   long long work_stride = 0;
   std::string err;
 };
@@ -107,6 +112,9 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   a.x = s->dx; a.mu_x = s->dmux; a.mu_lc = s->dmulc;
   a.n_iter = s->dniter; a.flags = s->dflags; a.metrics = s->dmetrics;
   a.factor_ticks = s->dticks; a.phase_ticks = s->dphase; a.workspace = s->dwork; a.workspace_stride = s->work_stride;
+  const bool fb = s->fallback && !s->warm_start;   // the presolve only runs on a cold start
+  a.fb_list = fb ? s->dfb_list : nullptr; a.fb_count = fb ? s->dfb_count : nullptr;
+  a.inst_list = nullptr; a.inst_count = nullptr;
 
   const bool want_fused = s->kernel_request != FCCQP_KERNEL_GENERIC;
   const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s) && fccqp::fused_pointers_ok(a);
@@ -114,6 +122,7 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     return fail(s, FCCQP_ERR_UNSUPPORTED,
                 "no fused kernel for this shape, or Q / A_eq not 16-byte aligned");
   HIP_TRY(s, hipEventRecord(s->ev0, stream));
+  if (fb) HIP_TRY(s, hipMemsetAsync(s->dfb_count, 0, sizeof(int), stream));
   hipError_t e;
   if (want_fused && can_fuse) {
     s->kernel_used = FCCQP_KERNEL_FUSED;
@@ -123,6 +132,17 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     e = fccqp::launch_generic(a, s->lds_limit, stream);
   }
   if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "kernel launch", e);
+  if (fb) {
+    // fallback pass over the (normally empty) device list: COD x0, then ADMM from it
+    const int blocks = fccqp_solver::kFallbackBlocks < s->batch ? fccqp_solver::kFallbackBlocks : s->batch;
+    e = fccqp::launch_cod(a, s->dfb_list, s->dfb_count, s->dcod_ws, s->cod_stride, blocks, stream);
+    if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "fallback (COD) kernel launch", e);
+    fccqp::KernelArgs b = a;
+    b.fb_list = nullptr; b.fb_count = nullptr;
+    b.inst_list = s->dfb_list; b.inst_count = s->dfb_count;
+    e = fccqp::launch_generic_list(b, s->lds_limit, blocks, stream);
+    if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "fallback (ADMM) kernel launch", e);
+  }
   HIP_TRY(s, hipEventRecord(s->ev1, stream));
   s->last_stream = stream;
   s->last_was_warm = s->warm_start;
@@ -212,6 +232,11 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
     HIP_TRY(s, hipMemset(s->dticks, 0, sizeof(long long) * B));
     s->work_stride = fccqp::generic_workspace_doubles(num_vars, num_equality_constraints, nc, lds);
     if (s->work_stride > 0) HIP_TRY(s, dmalloc(&s->dwork, B * (size_t)s->work_stride));
+    HIP_TRY(s, dmalloc(&s->dfb_list, B));
+    HIP_TRY(s, dmalloc(&s->dfb_count, 1));
+    HIP_TRY(s, hipMemset(s->dfb_count, 0, sizeof(int)));
+    s->cod_stride = fccqp::cod_workspace_doubles(num_vars, num_equality_constraints);
+    HIP_TRY(s, dmalloc(&s->dcod_ws, (size_t)fccqp_solver::kFallbackBlocks * (size_t)s->cod_stride));
     return FCCQP_OK;
   }();
   if (rc != FCCQP_OK) {
@@ -228,7 +253,8 @@ int fccqp_destroy(fccqp_solver *s) {
   DeviceGuard g(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, s->dx, s->dmux, s->dmulc,
-                  s->dmetrics, s->dwork, s->dniter, s->dflags, s->dticks, s->dphase};
+                  s->dmetrics, s->dwork, s->dniter, s->dflags, s->dticks, s->dphase, s->dfb_list,
+                  s->dfb_count, s->dcod_ws};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -258,6 +284,11 @@ int fccqp_set_warm_start(fccqp_solver *s, int warm_start) {
 int fccqp_set_kernel(fccqp_solver *s, int kernel) {
   if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_FUSED) return FCCQP_ERR_INVALID_ARG;
   s->kernel_request = kernel;
+  return FCCQP_OK;
+}
+int fccqp_set_presolve_fallback(fccqp_solver *s, int enabled) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  s->fallback = enabled != 0;
   return FCCQP_OK;
 }
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {

@@ -23,6 +23,14 @@ struct KernelArgs {
   int *flags;             // [batch]  FCCQP_FLAG_*
   double *metrics;        // [4][batch] residual_bounds, residual_cone, bounds_viol, cone_viol
   long long *factor_ticks;  // [batch] 100 MHz ticks spent factorising
+  // rank-deficient presolve fallback (fccqp_cod.hip): instances whose presolve LDL^T met a zero /
+  // non-finite pivot are appended to fb_list (count in *fb_count) and left for the fallback pass
+  int *fb_list;            // [batch] or null (then such instances just carry the flag)
+  int *fb_count;
+  // list mode (generic kernel only): process inst_list[0..*inst_count) instead of blockIdx.x,
+  // taking x0 from a.x (presolve already done by the fallback)
+  const int *inst_list;
+  const int *inst_count;
   long long *phase_ticks;  // optional [8][batch]: 100 MHz ticks per phase (fused kernel), or null
   double *workspace;      // generic kernel, large shapes: per-block packed KKT in global memory
   long long workspace_stride;  // doubles per block
@@ -33,6 +41,7 @@ constexpr int kFlagPresolveRan = 1;
 constexpr int kFlagPresolveNumerical = 2;
 constexpr int kFlagAdmmNumerical = 4;
 constexpr int kFlagEqualityOnly = 8;
+constexpr int kFlagPresolveCod = 16;
 
 // ---- generic kernel (fccqp_generic.hip) -----------------------------------------------------
 // Largest KKT size N = n + m the generic kernel handles (8 register slots x 64 lanes).
@@ -42,6 +51,13 @@ size_t generic_lds_bytes(int n, int m, int nc);
 // Doubles of global workspace per block when the packed KKT does not fit in LDS (else 0).
 long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit);
 hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream);
+// list mode: a.inst_list / a.inst_count set; `blocks` persistent one-wave workgroups
+hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream);
+
+// ---- presolve fallback (fccqp_cod.hip) -----------------------------------------------------------
+long long cod_workspace_doubles(int n, int m);
+hipError_t launch_cod(const KernelArgs &a, const int *list, const int *count, double *ws,
+                      long long ws_stride, int blocks, hipStream_t stream);
 
 // ---- fused shape-specialised kernels (fccqp_fused.hip) ---------------------------------------
 bool fused_supported(int n, int m, int nc, int s);

@@ -243,11 +243,13 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
   const int rel = lane - lane0;            // position of this lane's diagonal-block row in the panel
   bool bad_any = false;
   double dmine = 1.0, rmine = 0.0;
+  const int ncol = (N - c0 < P) ? N - c0 : P;   // columns that exist (the last panel may be short)
 #pragma unroll
   for (int k = 0; k < P; ++k) {
     const double d = bcast_lane(USE0 ? T0[k] : T1[k], lane0 + k);
-    // zero, infinite or NaN pivot (class mask: sNaN|qNaN|-inf|-0|+0|+inf)
-    bad_any |= __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
+    // zero, infinite or NaN pivot (class mask: sNaN|qNaN|-inf|-0|+0|+inf); columns past N in a
+    // short last panel hold garbage that is computed on (no branch) but neither judged nor stored
+    bad_any |= (k < ncol) & __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
     const double rinv = fast_rcp(d);
     dmine = (rel == k) ? d : dmine;
     rmine = (rel == k) ? ((fabs(d) > DBL_MIN) ? rinv : 0.0) : rmine;
@@ -255,19 +257,23 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
     if constexpr (USE0) T0[k] = a0 * rinv;
     T1[k] = a1 * rinv;
     const double lsrc = USE0 ? T0[k] : T1[k];
-    // rank-1 update of the panel columns to the right:  T[i][jj] -= a_i * l_{c0+jj, j}
+    // rank-1 update of the panel columns to the right:  T[i][jj] -= a_i * l_{c0+jj, j}.
+    // The scalar for column jj+1 is read (v_readlane pair) before the FMAs of column jj, which
+    // fills the wait states between a v_readlane and the VALU that consumes its SGPRs; the empty
+    // asm keeps this order -- left alone the scheduler separates the two FMAs of a scalar and
+    // spills every scalar to a VGPR lane (v_writelane + s_nop) to read it back later.
+    double lcur = (k + 1 < P) ? bcast_lane(lsrc, lane0 + k + 1) : 0.0;
 #pragma unroll
     for (int jj = k + 1; jj < P; ++jj) {
-      const double ljj = bcast_lane(lsrc, lane0 + jj);
-      if constexpr (USE0) T0[jj] = fma(-a0, ljj, T0[jj]);
-      T1[jj] = fma(-a1, ljj, T1[jj]);
-      // keep both consumers of the scalar next to its v_readlane pair: left alone the scheduler
-      // separates them and every scalar is spilled to a VGPR lane (v_writelane + s_nop) and read back
-      if constexpr (USE0) asm volatile("" : "+v"(T0[jj]), "+v"(T1[jj]));
+      double lnext = (jj + 1 < P) ? bcast_lane(lsrc, lane0 + jj + 1) : 0.0;
+      if constexpr (USE0) T0[jj] = fma(-a0, lcur, T0[jj]);
+      T1[jj] = fma(-a1, lcur, T1[jj]);
+      if constexpr (USE0) asm volatile("" : "+v"(T0[jj]), "+v"(T1[jj]), "+s"(lnext));
+      else asm volatile("" : "+v"(T1[jj]), "+s"(lnext));
+      lcur = lnext;
     }
   }
   // (d) write the panel back: rows below the diagonal block take all 16 columns ...
-  const int ncol = (N - c0 < P) ? N - c0 : P;   // columns that exist (last panel may be short)
   if constexpr (USE0) {
     if (row0 >= c0 + P && row0 < N) {
 #pragma unroll
@@ -473,6 +479,15 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     ticks += wall_clock64() - t0;
     if (pass == 0) {
       flags |= kFlagPresolveRan | (bad ? kFlagPresolveNumerical : 0);
+      if (bad && a.fb_list) {
+        // where the reference switches to its COD fallback (fcc_qp.cpp:164-166): hand the instance
+        // to the fallback pass (fccqp_cod.hip + generic kernel in list mode) and stop here
+        if (lane == 0) {
+          a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
+          a.flags[inst] = flags;
+        }
+        return;
+      }
       // x_ = (K^-1 [-b; b_eq]).head(n)   (fcc_qp.cpp:149-150,174)
       stage_rhs();
       double r0 = (lane < N) ? vbuf[lane < N ? lane : 0] : 0.0;

@@ -165,12 +165,11 @@ __device__ __forceinline__ void project_cone3(double fx, double fy, double fz, d
   ox = dot * rx; oy = dot * ry; oz = dot * rz;
 }
 
+// Solves instance `inst`.  x0_given: the presolve was done elsewhere (fallback pass): x0 comes from
+// a.x, the duals start at zero, the presolve flags are reported as "ran, numerical, COD".
 template <int SLOTS, bool MAT_IN_LDS>
-__global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ void solve_instance(const KernelArgs &a, double *lds, const int inst, const bool x0_given) {
   const int lane = threadIdx.x;
-  const int inst = blockIdx.x;
-  if (inst >= a.batch) return;
   const int n = a.n, m = a.m, nc = a.nc, s0 = a.s, N = n + m;
   const int npack = (N * (N + 1)) / 2;
 
@@ -202,7 +201,9 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
     vtail[t] = (i >= n && i < N) ? beq[i - n] : 0.0;
     is_cone[t] = (i >= s0 && i < s0 + nc);
     if (i < n) all_inf = all_inf && isinf(vlb[t]) && isinf(vub[t]);  // fcc_qp.cpp:132-133
-    if (a.warm_start) {                                            // :136-139
+    if (x0_given) {
+      x[t] = (i < n) ? xs[i] : 0.0; mux[t] = 0.0; mulc[t] = 0.0;
+    } else if (a.warm_start) {                                     // :136-139
       x[t] = (i < n) ? xs[i] : 0.0;
       mux[t] = (i < n) ? mux_s[i] : 0.0;
       mulc[t] = is_cone[t] ? mulc_s[i - s0] : 0.0;
@@ -230,13 +231,26 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
   };
 
   // ---- presolve (fcc_qp.cpp:159-178): skipped on warm start unless equality-only ---------
-  if (equality_constrained || !a.warm_start) {
+  if (x0_given) {
+    flags |= kFlagPresolveRan | kFlagPresolveNumerical | kFlagPresolveCod;
+  } else if (equality_constrained || !a.warm_start) {
     flags |= kFlagPresolveRan;
     assemble(0.0);
     const long long t0 = wall_clock64();
     const bool bad = ldlt_factor<SLOTS>(M, N, lane);
     ticks += wall_clock64() - t0;
-    if (bad) flags |= kFlagPresolveNumerical;
+    if (bad) {
+      flags |= kFlagPresolveNumerical;
+      if (a.fb_list) {
+        // where the reference switches to its COD fallback (fcc_qp.cpp:164-166): hand the
+        // instance to the fallback pass and stop here
+        if (lane == 0) {
+          a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
+          a.flags[inst] = flags;
+        }
+        return;
+      }
+    }
     double r[SLOTS];
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) {
@@ -374,11 +388,23 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
   }
 }
 
+template <int SLOTS, bool MAT_IN_LDS>
+__global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  if (a.inst_list) {  // list mode: persistent blocks walk the fallback list
+    const int total = *a.inst_count;
+    for (int li = blockIdx.x; li < total; li += gridDim.x)
+      solve_instance<SLOTS, MAT_IN_LDS>(a, lds, a.inst_list[li], true);
+  } else if ((int)blockIdx.x < a.batch) {
+    solve_instance<SLOTS, MAT_IN_LDS>(a, lds, (int)blockIdx.x, false);
+  }
+}
+
 inline int slots_for(int N) { return (N + kWave - 1) / kWave; }
 
 template <int SLOTS>
-hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, hipStream_t stream) {
-  dim3 grid(a.batch), block(kWave);
+hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, int blocks, hipStream_t stream) {
+  dim3 grid(blocks), block(kWave);
   if (mat_in_lds) {
     auto k = generic_kernel<SLOTS, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
@@ -405,20 +431,28 @@ long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {
   return N * (N + 1) / 2 + 8;
 }
 
-hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream) {
+static hipError_t launch_generic_blocks(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream) {
   const int N = a.n + a.m;
   if (N > kGenericMaxN) return hipErrorInvalidValue;
-  if (a.batch <= 0) return hipSuccess;
+  if (a.batch <= 0 || blocks <= 0) return hipSuccess;
   const bool in_lds = generic_lds_bytes(a.n, a.m, a.nc) <= lds_limit;
   const size_t lds = in_lds ? generic_lds_bytes(a.n, a.m, a.nc) : sizeof(double) * ((size_t)a.nc + 2);
   const int slots = slots_for(N > 0 ? N : 1);
   switch (slots) {
-    case 1: return launch_slots<1>(a, in_lds, lds, stream);
-    case 2: return launch_slots<2>(a, in_lds, lds, stream);
-    case 3: return launch_slots<3>(a, in_lds, lds, stream);
-    case 4: return launch_slots<4>(a, in_lds, lds, stream);
-    default: return launch_slots<8>(a, in_lds, lds, stream);
+    case 1: return launch_slots<1>(a, in_lds, lds, blocks, stream);
+    case 2: return launch_slots<2>(a, in_lds, lds, blocks, stream);
+    case 3: return launch_slots<3>(a, in_lds, lds, blocks, stream);
+    case 4: return launch_slots<4>(a, in_lds, lds, blocks, stream);
+    default: return launch_slots<8>(a, in_lds, lds, blocks, stream);
   }
+}
+
+hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream) {
+  return launch_generic_blocks(a, lds_limit, a.batch, stream);
+}
+
+hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream) {
+  return launch_generic_blocks(a, lds_limit, blocks, stream);
 }
 
 }  // namespace fccqp

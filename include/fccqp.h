@@ -59,10 +59,13 @@ enum { FCCQP_STATUS_SUCCESS = 0, FCCQP_STATUS_MAX_ITERATIONS = 1 };
 enum {
   FCCQP_FLAG_PRESOLVE_RAN = 1,          /* presolve branch of fcc_qp.cpp:159 executed            */
   FCCQP_FLAG_PRESOLVE_NUMERICAL = 2,    /* presolve LDL^T met a zero / non-finite pivot: where
-                                           the reference would switch to its COD fallback
-                                           (fcc_qp.cpp:164-166); z is then NOT comparable       */
+                                           the reference switches to its COD fallback
+                                           (fcc_qp.cpp:164-166).  Without FLAG_PRESOLVE_COD
+                                           (fallback disabled) z is NOT comparable              */
   FCCQP_FLAG_ADMM_NUMERICAL = 4,        /* ADMM LDL^T met a zero / non-finite pivot              */
-  FCCQP_FLAG_EQUALITY_ONLY = 8          /* nc == 0 and all bounds infinite: no ADMM (:132-133)   */
+  FCCQP_FLAG_EQUALITY_ONLY = 8,         /* nc == 0 and all bounds infinite: no ADMM (:132-133)   */
+  FCCQP_FLAG_PRESOLVE_COD = 16          /* x0 came from the device COD fallback (min-norm least
+                                           squares, fcc_qp.cpp:165,176): z IS comparable again   */
 };
 
 /* kernel selection */
@@ -115,6 +118,10 @@ int fccqp_set_options(fccqp_solver *s, const fccqp_options *opt);
 int fccqp_get_options(const fccqp_solver *s, fccqp_options *opt);
 int fccqp_set_warm_start(fccqp_solver *s, int warm_start);
 int fccqp_set_kernel(fccqp_solver *s, int kernel);   /* FCCQP_KERNEL_* */
+/* Rank-deficient presolve fallback on the device (replaces the CompleteOrthogonalDecomposition
+ * branch, reference src/fcc_qp.cpp:164-166,176).  On by default; costs two near-empty kernel
+ * launches per solve when no instance needs it. */
+int fccqp_set_presolve_fallback(fccqp_solver *s, int enabled);
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use);
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
                     int *lambda_c_start, int *batch, int *device);

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "fccqp.h")
 
 OK, ERR_INVALID_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_FRICTION, ERR_NOT_SOLVED, ERR_UNSUPPORTED = range(9)
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FUSED = 0, 1, 2
-FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY = 1, 2, 4, 8
+FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD = 1, 2, 4, 8, 16
 
 
 class Options(C.Structure):
@@ -57,6 +57,7 @@ def lib():
         L.fccqp_default_options.argtypes = [C.POINTER(Options)]
         L.fccqp_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_set_kernel.argtypes = [C.c_void_p, C.c_int]
+        L.fccqp_set_presolve_fallback.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_get_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.fccqp_solve.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.fccqp_solve_device.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]
@@ -108,6 +109,9 @@ class Solver:
 
     def set_kernel(self, k):
         self._ck(self.L.fccqp_set_kernel(self.h, int(k)), "set_kernel")
+
+    def set_presolve_fallback(self, on):
+        self._ck(self.L.fccqp_set_presolve_fallback(self.h, int(bool(on))), "set_presolve_fallback")
 
     def kernel(self):
         k = C.c_int()

@@ -188,3 +188,61 @@ def test_batch_4096_properties(oracle):
     sl = B.slice(0, 256)
     z_ref, it_ref, _ = oracle_batch(oracle, P.WALKING.ctor_args, P.HARNESS_OPTIONS, sl)
     assert_parity(z[:256], it[:256], z_ref, it_ref, tol=Z_TOL_TIGHT, what="4096 sample")
+
+
+# ---- rank-deficient presolve: the reference's COD fallback (fcc_qp.cpp:164-166,176) on the device ----
+def _dead_variable(qp, j):
+    """Variable j gets no cost and no constraint: K has a zero row -> exactly singular."""
+    q = {k: np.array(v, copy=True) for k, v in qp.items()}
+    q["Q"][j, :] = 0.0; q["Q"][:, j] = 0.0; q["A_eq"][:, j] = 0.0; q["b"][j] = 0.0
+    return q
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_rank_deficient_presolve_uses_device_cod(oracle, kernel):
+    base = P.workload("W-mix", 12, P.WALKING)
+    qps = [base.instance(i) for i in range(12)]
+    singular = {2: 25, 7: 30, 8: 23}                      # instance -> dead actuator variable
+    for i, j in singular.items():
+        qps[i] = _dead_variable(qps[i], j)
+    B = P.stack(qps)
+    z_ref, it_ref, det_ref = oracle_batch(oracle, P.WALKING.ctor_args, P.HARNESS_OPTIONS, B)
+    for i in range(12):
+        assert det_ref[i].presolve_ldlt_info == (1 if i in singular else 0)   # the oracle took the COD branch
+    z, it, d, s = gpu_solve(P.WALKING, P.HARNESS_OPTIONS, B, kernel)
+    assert_parity(z, it, z_ref, it_ref, tol=Z_TOL, what="cod fallback")
+    for i in range(12):
+        cod = bool(d[i].flags & CAPI.FLAG_PRESOLVE_COD)
+        assert cod == (i in singular)
+        assert bool(d[i].flags & CAPI.FLAG_PRESOLVE_NUMERICAL) == (i in singular)
+        assert d[i].flags & CAPI.FLAG_PRESOLVE_RAN
+    # instances that did not need the fallback are bit-identical with the fallback switched off
+    s2 = CAPI.Solver(*P.WALKING.ctor_args, batch=12); s2.set_presolve_fallback(False)
+    z2, it2, d2, _ = gpu_solve(P.WALKING, P.HARNESS_OPTIONS, B, kernel, solver=s2)
+    ok = [i for i in range(12) if i not in singular]
+    assert np.array_equal(z2[ok], z[ok]) and np.array_equal(it2[ok], it[ok])
+    for i in singular:
+        assert d2[i].flags & CAPI.FLAG_PRESOLVE_NUMERICAL and not (d2[i].flags & CAPI.FLAG_PRESOLVE_COD)
+
+
+def test_cod_fallback_equality_only_is_the_pseudo_inverse(oracle):
+    """nc == 0, infinite bounds, semi-definite cost: x = (pinv(K) [-b; b_eq]).head(n), n_iter = 0."""
+    n, m = 6, 2
+    Q = np.diag([1.0, 2.0, 0.0, 0.0, 3.0, 0.0])
+    A = np.array([[1.0, 0, 1, 0, 0, 0], [0, 1.0, 0, 0, 1, 0]])
+    b = np.array([1.0, -1, 0, 0, 0.5, 0]); beq = np.array([1.0, 2.0])
+    inf = np.full(n, np.inf)
+    s = CAPI.Solver(n, m, 0, 0, batch=3); s.set_options(10, 1e-3, 1e-6, 1e-6)
+    Qs = np.stack([Q, Q + np.eye(n), Q]); bs = np.stack([b, b, 2 * b])
+    s.solve_ok(Qs, bs, np.stack([A] * 3), np.stack([beq] * 3), np.zeros((3, 0)), np.stack([-inf] * 3), np.stack([inf] * 3))
+    z, d = s.solution()
+    K = np.block([[Q, A.T], [A, np.zeros((m, m))]])
+    assert np.allclose(z[0], (np.linalg.pinv(K) @ np.r_[-b, beq])[:n], rtol=1e-9, atol=1e-9)
+    assert np.allclose(z[2], (np.linalg.pinv(K) @ np.r_[-2 * b, beq])[:n], rtol=1e-9, atol=1e-9)
+    K1 = np.block([[Q + np.eye(n), A.T], [A, np.zeros((m, m))]])
+    assert np.allclose(z[1], np.linalg.solve(K1, np.r_[-b, beq])[:n], rtol=1e-9, atol=1e-9)
+    assert [bool(x.flags & CAPI.FLAG_PRESOLVE_COD) for x in d] == [True, False, True]
+    assert all(x.n_iter == 0 and x.flags & CAPI.FLAG_EQUALITY_ONLY for x in d)
+    o = oracle.OracleFCCQP(n, m, 0, 0); op = oracle.FCCQPOptions(); op.max_iter = 10; o.set_options(op)
+    o.Solve(Q, b, A, beq, [], -inf, inf)
+    assert np.allclose(o.GetSolution().z, z[0], rtol=1e-9, atol=1e-9)

@@ -119,11 +119,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal aid: FCCQP_BENCH_ALL_ON_DEVICE0=1 lets several ranks share one GPU (1-GPU dev box)
+    dev_index = 0 if os.environ.get("FCCQP_BENCH_ALL_ON_DEVICE0") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = "gloo" if os.environ.get("FCCQP_BENCH_ALL_ON_DEVICE0") == "1" else "nccl"
+        dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import fcc_qp_amd as F
     from fcc_qp_amd import problems as P
@@ -135,7 +138,7 @@ def main():
     batch = P.workload(args.workload, nb, shape, seed0=S.rank_seed0(rank, nb))   # instance i: seed 1000 + i
     log(f"[bench] generated {nb} '{args.workload}' instances per rank in {time.time() - t0:.1f} s")
 
-    solver = F.FCCQPBatch(*shape.ctor_args, nb, local_rank)
+    solver = F.FCCQPBatch(*shape.ctor_args, nb, dev_index)
     o = F.FCCQPOptions()
     o.max_iter, o.rho, o.eps_fcone, o.eps_bound = (options["max_iter"], options["rho"],
                                                    options["eps_fcone"], options["eps_bound"])
@@ -183,8 +186,9 @@ def main():
     elapsed = time.perf_counter() - t_start
     kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]        # HIP events on the launch stream
 
-    elapsed = S.max_over_ranks(elapsed, dev)          # the slowest rank defines the step time
-    solved = S.sum_over_ranks(float(nb * args.steps), dev)
+    red_dev = dev if (world > 1 and dist.get_backend() == "nccl") else None
+    elapsed = S.max_over_ranks(elapsed, red_dev)      # the slowest rank defines the step time
+    solved = S.sum_over_ranks(float(nb * args.steps), red_dev)
 
     if rank == 0:
         value = solved / elapsed

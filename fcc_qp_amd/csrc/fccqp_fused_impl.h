@@ -107,35 +107,48 @@ __device__ __forceinline__ double wave_max(double v) {
   return bcast_lane(v, 63);
 }
 
-// reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25.
-// Same three branches and the same f_z == 0 quirk; the side-of-cone branch evaluates
-// (r.f / r.r) r instead of normalising r first ((r/|r|).f (r/|r|), :22-23): identical in exact
-// arithmetic, one division instead of three plus a square root (fp64 div/sqrt are ~15-instruction
-// sequences that every lane of the wave executes), a few ulp apart in floating point.
-__device__ __forceinline__ void project_cone3(double fx, double fy, double fz, double mu,
-                                              double &ox, double &oy, double &oz) {
-  const double nxy = sqrt(fx * fx + fy * fy);
-  const bool inside = mu * fz >= nxy;        // :10-12
-  const bool polar = fz < -mu * nxy;         // :15-17
-  const double ratio = mu * fz / nxy;        // :20
-  const double rx = ratio * fx, ry = ratio * fy, rz = fz;
-  const double z2 = rx * rx + ry * ry + rz * rz;
-  const double dot = rx * fx + ry * fy + rz * fz;
-  const double sc = (z2 > 0.0) ? dot / z2 : 0.0;   // Eigen normalize() leaves a zero ray untouched -> 0
-  ox = inside ? fx : (polar ? 0.0 : sc * rx);
-  oy = inside ? fy : (polar ? 0.0 : sc * ry);
-  oz = inside ? fz : (polar ? 0.0 : sc * rz);
-}
-
-// 1/d by v_rcp_f64 + two Newton steps: <= 1 ulp from the correctly rounded quotient, a third of the
-// dependent-instruction chain of an IEEE division (the pivot reciprocal sits on the critical path
-// of every factorisation step).
+// reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25, evaluated for ONE
+// component of the contact force (every lane of a contact triple calls it with the same
+// (fx, fy, fz) and its own component v = f[comp]).  Same three branches and the same f_z == 0
+// quirk.  The side-of-cone branch evaluates (r.f / r.r) r instead of normalising r first
+// ((r/|r|).f (r/|r|), :22-23) -- identical in exact arithmetic -- and gets 1/|f_xy| and 1/(r.r)
+// from v_rsq_f64 / v_rcp_f64 + Newton steps (<= 1-2 ulp) instead of IEEE sqrt/div: those are
+// ~15-instruction sequences executed by every lane of the wave on every ADMM iteration.
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.0), r, r);
   r = fma(fma(-d, r, 1.0), r, r);
   return r;
 }
+__device__ __forceinline__ double fast_rsqrt(double a) {  // a > 0
+  double r = __builtin_amdgcn_rsq(a);
+  // Newton for 1/sqrt(a): r <- r + r * (1 - a r^2) / 2, twice
+  double e = fma(-a * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-a * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  return r;
+}
+__device__ __forceinline__ double project_cone_component(double fx, double fy, double fz, double mu,
+                                                         double v, bool is_z) {
+  const double nxy2 = fx * fx + fy * fy;
+  const bool flat = !(nxy2 > 0.0);                      // f_xy == 0: inside if f_z >= 0, else origin
+  const double rs = fast_rsqrt(flat ? 1.0 : nxy2);
+  const double nxy = flat ? 0.0 : nxy2 * rs;
+  const bool inside = mu * fz >= nxy;                   // :10-12
+  const bool polar = fz < -mu * nxy;                    // :15-17
+  const double ratio = mu * fz * rs;                    // :20   mu f_z / |f_xy|
+  // ray r = (ratio fx, ratio fy, fz):  r.r = ratio^2 |f_xy|^2 + fz^2,  r.f = ratio |f_xy|^2 + fz^2
+  const double fz2 = fz * fz;
+  const double z2 = fma(ratio * ratio, nxy2, fz2);
+  const double dot = fma(ratio, nxy2, fz2);
+  const double sc = (z2 > 0.0) ? dot * fast_rcp(z2) : 0.0;   // zero ray (f_z == 0): Eigen's normalize() no-op -> 0
+  const double side = sc * (is_z ? 1.0 : ratio) * v;
+  return inside ? v : (polar ? 0.0 : side);
+}
+
+// (fast_rcp above is also the pivot reciprocal of the factorisation: <= 1 ulp from the correctly
+// rounded quotient, a third of the dependent-instruction chain of an IEEE division.)
 
 // ---- compile-time shape description ------------------------------------------------------------
 template <int N_VARS, int N_EQ, int NC, int LC_START>
@@ -582,9 +595,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       }
       if (is_cone) {
         const int base = s0 + 3 * cidx;
-        double ox, oy, oz;
-        project_cone3(vbuf[base], vbuf[base + 1], vbuf[base + 2], vmu, ox, oy, oz);
-        lcbar = (ccomp == 0) ? ox : ((ccomp == 1) ? oy : oz);
+        lcbar = project_cone_component(vbuf[base], vbuf[base + 1], vbuf[base + 2], vmu, x + mulc, ccomp == 2);
         lr = x - lcbar;                   // :96
         mulc += lr;                       // :102
       }

@@ -246,3 +246,44 @@ def test_cod_fallback_equality_only_is_the_pseudo_inverse(oracle):
     o = oracle.OracleFCCQP(n, m, 0, 0); op = oracle.FCCQPOptions(); op.max_iter = 10; o.set_options(op)
     o.Solve(Q, b, A, beq, [], -inf, inf)
     assert np.allclose(o.GetSolution().z, z[0], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_cone_projection_branches_and_fz_zero_quirk(oracle, kernel):
+    """Every branch of project_to_friction_cone (constraint_utils.cpp:5-25) through one ADMM
+    iteration on the mini shape FCCQP(12,5,6,3) (fused kernel under AUTO): Q = I and equality rows
+    that do not touch the contact variables make the first iterate x[3:9] = -b[3:9] exactly, so the
+    cone inputs are chosen by b.  Compared through the duals mu_lambda_c = x - lambda_c_bar."""
+    n, m, nc, s0 = 12, 5, 6, 3
+    A = np.zeros((m, n))
+    for r, j in enumerate((0, 1, 2, 9, 10)):
+        A[r, j] = 1.0
+    cases = {
+        "inside":        ([0.3, -0.4, 1.0], [0.1, 0.0, 2.0]),
+        "polar":         ([0.1, 0.0, -1.0], [-0.2, 0.1, -3.0]),
+        "side":          ([3.0, 4.0, 1.0], [1.0, -2.0, 0.5]),
+        "fz_zero_quirk": ([1.0, 0.0, 0.0], [0.0, 2.0, 0.0]),      # -> 0, not the true projection
+        "flat":          ([0.0, 0.0, 2.0], [0.0, 0.0, -2.0]),
+        "side_negative_fz": ([3.0, 0.0, -1.0], [0.0, 5.0, -0.1]),
+    }
+    qps = []
+    for f1, f2 in cases.values():
+        b = np.zeros(n); b[3:6] = -np.array(f1); b[6:9] = -np.array(f2)
+        qps.append(dict(Q=np.eye(n), b=b, A_eq=A, b_eq=np.zeros(m), friction_coeffs=np.array([0.6, 0.5]),
+                        lb=np.full(n, -np.inf), ub=np.full(n, np.inf)))
+    B = P.stack(qps)
+    opts = dict(max_iter=1, rho=0.25, eps_fcone=1e-12, eps_bound=1e-12)
+    s = CAPI.Solver(n, m, nc, s0, batch=len(qps)); s.set_options(**opts); s.set_kernel(kernel)
+    s.solve_ok(*B.arrays())
+    z, d = s.solution()
+    x, mux, mulc = s.state()
+    for i, (name, qp) in enumerate(zip(cases, qps)):
+        o = oracle.OracleFCCQP(n, m, nc, s0)
+        op = oracle.FCCQPOptions(); op.__dict__.update(opts); o.set_options(op)
+        o.Solve(**qp)
+        xo, mo, lo = o.get_state()
+        assert np.max(np.abs(mulc[i] - lo)) <= 1e-12 * (1 + np.max(np.abs(lo))), name
+        assert np.max(np.abs(z[i] - xo)) <= 1e-12 * (1 + np.max(np.abs(xo))), name
+    # the quirk itself: lambda_c_bar == 0 for (1, 0, 0)  =>  mu_lambda_c == x
+    iq = list(cases).index("fz_zero_quirk")
+    assert np.allclose(mulc[iq][:3], z[iq][3:6], rtol=0, atol=1e-15) and abs(z[iq][3] - 1.0) < 1e-12

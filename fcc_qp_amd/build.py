@@ -66,8 +66,9 @@ def generate_p3(force: bool = False) -> List[str]:
 
 def build_lib(force: bool = False) -> str:
     incs = generate_p3(force)
-    srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip", "fccqp_cod.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip")]
     deps = srcs + incs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
+                          os.path.join(CSRC, "fccqp_cod_impl.h"),
                           os.path.join(ROOT, "include", "fccqp.h")]
     if force or _newer(LIB, deps):
         objs = []

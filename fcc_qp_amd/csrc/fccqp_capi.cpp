@@ -40,7 +40,8 @@ struct fccqp_solver {
   long long *dticks = nullptr;
   long long *dphase = nullptr;  // [8][batch], allocated on demand
   bool fallback = true;          // device COD fallback for a rank-deficient presolve
-  int *dfb_list = nullptr, *dfb_count = nullptr;
+  int *dfb_list = nullptr, *dfb_count = nullptr;  // dfb_count[2]: used alternately, see enqueue()
+  unsigned solve_seq = 0;
   double *dcod_ws = nullptr;
   long long cod_stride = 0;
   static constexpr int kFallbackBlocks = 64;
@@ -113,8 +114,10 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   a.n_iter = s->dniter; a.flags = s->dflags; a.metrics = s->dmetrics;
   a.factor_ticks = s->dticks; a.phase_ticks = s->dphase; a.workspace = s->dwork; a.workspace_stride = s->work_stride;
   const bool fb = s->fallback && !s->warm_start;   // the presolve only runs on a cold start
-  a.fb_list = fb ? s->dfb_list : nullptr; a.fb_count = fb ? s->dfb_count : nullptr;
-  a.inst_list = nullptr; a.inst_count = nullptr;
+  int *cnt = s->dfb_count + (s->solve_seq & 1u), *cnt_next = s->dfb_count + ((s->solve_seq + 1u) & 1u);
+  a.fb_list = fb ? s->dfb_list : nullptr; a.fb_count = fb ? cnt : nullptr;
+  a.inst_list = nullptr; a.inst_count = nullptr; a.next_count = nullptr;
+  a.cod_ws = s->dcod_ws; a.cod_stride = s->cod_stride;
 
   const bool want_fused = s->kernel_request != FCCQP_KERNEL_GENERIC;
   const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s) && fccqp::fused_pointers_ok(a);
@@ -122,7 +125,6 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     return fail(s, FCCQP_ERR_UNSUPPORTED,
                 "no fused kernel for this shape, or Q / A_eq not 16-byte aligned");
   HIP_TRY(s, hipEventRecord(s->ev0, stream));
-  if (fb) HIP_TRY(s, hipMemsetAsync(s->dfb_count, 0, sizeof(int), stream));
   hipError_t e;
   if (want_fused && can_fuse) {
     s->kernel_used = FCCQP_KERNEL_FUSED;
@@ -133,15 +135,15 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   }
   if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "kernel launch", e);
   if (fb) {
-    // fallback pass over the (normally empty) device list: COD x0, then ADMM from it
+    // fallback launch over the (normally empty) device list: COD x0, then ADMM from it.  It also
+    // zeroes the other counter, which the next solve's main kernel will append to.
     const int blocks = fccqp_solver::kFallbackBlocks < s->batch ? fccqp_solver::kFallbackBlocks : s->batch;
-    e = fccqp::launch_cod(a, s->dfb_list, s->dfb_count, s->dcod_ws, s->cod_stride, blocks, stream);
-    if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "fallback (COD) kernel launch", e);
     fccqp::KernelArgs b = a;
     b.fb_list = nullptr; b.fb_count = nullptr;
-    b.inst_list = s->dfb_list; b.inst_count = s->dfb_count;
+    b.inst_list = s->dfb_list; b.inst_count = cnt; b.next_count = cnt_next;
     e = fccqp::launch_generic_list(b, s->lds_limit, blocks, stream);
-    if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "fallback (ADMM) kernel launch", e);
+    if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "fallback kernel launch", e);
+    s->solve_seq++;
   }
   HIP_TRY(s, hipEventRecord(s->ev1, stream));
   s->last_stream = stream;
@@ -233,9 +235,9 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
     s->work_stride = fccqp::generic_workspace_doubles(num_vars, num_equality_constraints, nc, lds);
     if (s->work_stride > 0) HIP_TRY(s, dmalloc(&s->dwork, B * (size_t)s->work_stride));
     HIP_TRY(s, dmalloc(&s->dfb_list, B));
-    HIP_TRY(s, dmalloc(&s->dfb_count, 1));
-    HIP_TRY(s, hipMemset(s->dfb_count, 0, sizeof(int)));
-    s->cod_stride = fccqp::cod_workspace_doubles(num_vars, num_equality_constraints);
+    HIP_TRY(s, dmalloc(&s->dfb_count, 2));
+    HIP_TRY(s, hipMemset(s->dfb_count, 0, 2 * sizeof(int)));
+    s->cod_stride = fccqp::cod_workspace_doubles_host(num_vars, num_equality_constraints);
     HIP_TRY(s, dmalloc(&s->dcod_ws, (size_t)fccqp_solver::kFallbackBlocks * (size_t)s->cod_stride));
     return FCCQP_OK;
   }();

@@ -1,11 +1,13 @@
-// fccqp_cod.hip -- presolve fallback for a rank-deficient / semi-definite KKT matrix, on the device.
+// fccqp_cod_impl.h -- presolve fallback for a rank-deficient / semi-definite KKT matrix, on the
+// device (included by fccqp_generic.hip, whose list-mode kernel calls cod_presolve()).
 //
 // Reference behaviour replaced (/root/reference/src/fcc_qp.cpp:164-166,173-177): when the presolve
 // LDL^T reports a numerical issue, the reference solves K x = [-b; b_eq] with
 // Eigen::CompleteOrthogonalDecomposition, i.e. takes the MINIMUM-NORM LEAST-SQUARES solution.
 // The main kernels detect the condition (zero / non-finite pivot), append the instance to a device
-// list and stop; this kernel computes the fallback x0 for every listed instance and the generic
-// kernel then runs the ADMM phase from it.  Nothing returns to the host in between.
+// list and stop; the fallback launch (generic kernel in list mode, a few persistent one-wave blocks)
+// computes this x0 for every listed instance and runs the ADMM phase from it.  Nothing returns to
+// the host in between.
 //
 // Algorithm (the published COD: column-pivoted Householder QR, rank from
 // |R_kk| > eps * N * max|R_kk|, a second Householder QR on the transposed leading rows,
@@ -14,12 +16,13 @@
 //
 // This is a rare path (exactly singular cost blocks): one wavefront per listed instance, matrix in
 // a global-memory workspace (L2-resident), written for clarity, not speed.
+#pragma once
 #include <cfloat>
 
 #include "fccqp_device.h"
 
 namespace fccqp {
-namespace {
+namespace cod {
 
 constexpr int kWave = 64;
 
@@ -73,12 +76,11 @@ __device__ void apply_reflector(const double *vess, double tau, double *y, int l
   wsync();
 }
 
-__global__ __launch_bounds__(kWave) void cod_kernel(const KernelArgs a, const int *list, const int *count,
-                                                    double *ws, long long ws_stride) {
+// Minimum-norm least-squares x0 of instance `inst` into a.x; W = this block's workspace
+// (cod_workspace_doubles(n, m) doubles).
+__device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
   const int lane = threadIdx.x;
   const int n = a.n, m = a.m, N = n + m;
-  const int total = *count;
-  double *W = ws + (long long)blockIdx.x * ws_stride;
   double *A = W;                                  // N x N, column-major: A[i + j*N]
   double *B = A + (size_t)N * N;                  // N x N scratch for the second QR
   double *c = B + (size_t)N * N;                  // Q^T rhs
@@ -87,9 +89,8 @@ __global__ __launch_bounds__(kWave) void cod_kernel(const KernelArgs a, const in
   double *tz = tau + N;
   double *y = tz + N;
   int *perm = reinterpret_cast<int *>(y + N);
+  {
 
-  for (int li = blockIdx.x; li < total; li += gridDim.x) {
-    const int inst = list[li];
     const double *Q = a.Q + (size_t)inst * n * n;
     const double *Ae = a.A + (size_t)inst * m * n;
     const double *bq = a.b + (size_t)inst * n;
@@ -233,17 +234,11 @@ __global__ __launch_bounds__(kWave) void cod_kernel(const KernelArgs a, const in
   }
 }
 
-}  // namespace
+}  // namespace cod
 
-long long cod_workspace_doubles(int n, int m) {
+inline long long cod_workspace_doubles(int n, int m) {
   const long long N = (long long)n + m;
   return 2 * N * N + 6 * N + 8;
-}
-
-hipError_t launch_cod(const KernelArgs &a, const int *list, const int *count, double *ws,
-                      long long ws_stride, int blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(cod_kernel, dim3(blocks), dim3(kWave), 0, stream, a, list, count, ws, ws_stride);
-  return hipGetLastError();
 }
 
 }  // namespace fccqp

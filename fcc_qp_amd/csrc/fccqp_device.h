@@ -27,10 +27,14 @@ struct KernelArgs {
   // non-finite pivot are appended to fb_list (count in *fb_count) and left for the fallback pass
   int *fb_list;            // [batch] or null (then such instances just carry the flag)
   int *fb_count;
-  // list mode (generic kernel only): process inst_list[0..*inst_count) instead of blockIdx.x,
-  // taking x0 from a.x (presolve already done by the fallback)
+  // list mode (generic kernel only, the fallback launch): for every instance in
+  // inst_list[0..*inst_count) compute the COD x0 in cod_ws, then run ADMM from it; *next_count is
+  // zeroed for the following solve (the two counters are used alternately: no memset)
   const int *inst_list;
   const int *inst_count;
+  int *next_count;
+  double *cod_ws;
+  long long cod_stride;
   long long *phase_ticks;  // optional [8][batch]: 100 MHz ticks per phase (fused kernel), or null
   double *workspace;      // generic kernel, large shapes: per-block packed KKT in global memory
   long long workspace_stride;  // doubles per block
@@ -54,10 +58,8 @@ hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t str
 // list mode: a.inst_list / a.inst_count set; `blocks` persistent one-wave workgroups
 hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream);
 
-// ---- presolve fallback (fccqp_cod.hip) -----------------------------------------------------------
-long long cod_workspace_doubles(int n, int m);
-hipError_t launch_cod(const KernelArgs &a, const int *list, const int *count, double *ws,
-                      long long ws_stride, int blocks, hipStream_t stream);
+// ---- presolve fallback workspace (fccqp_cod_impl.h) ---------------------------------------------
+long long cod_workspace_doubles_host(int n, int m);
 
 // ---- fused shape-specialised kernels (fccqp_fused.hip) ---------------------------------------
 bool fused_supported(int n, int m, int nc, int s);

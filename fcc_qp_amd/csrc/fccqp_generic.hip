@@ -20,6 +20,7 @@
 // This is the any-shape path and the first correct HIP path; the shape-specialised kernel in
 // fccqp_fused.hip is the fast one.
 #include "fccqp_device.h"
+#include "fccqp_cod_impl.h"
 
 #include <cfloat>
 
@@ -391,10 +392,14 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
 template <int SLOTS, bool MAT_IN_LDS>
 __global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  if (a.inst_list) {  // list mode: persistent blocks walk the fallback list
+  if (a.inst_list) {  // list mode (fallback launch): persistent blocks walk the fallback list
     const int total = *a.inst_count;
-    for (int li = blockIdx.x; li < total; li += gridDim.x)
-      solve_instance<SLOTS, MAT_IN_LDS>(a, lds, a.inst_list[li], true);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_count = 0;
+    for (int li = blockIdx.x; li < total; li += gridDim.x) {
+      const int inst = a.inst_list[li];
+      cod::cod_presolve(a, inst, a.cod_ws + (long long)blockIdx.x * a.cod_stride);   // fcc_qp.cpp:165,176
+      solve_instance<SLOTS, MAT_IN_LDS>(a, lds, inst, true);
+    }
   } else if ((int)blockIdx.x < a.batch) {
     solve_instance<SLOTS, MAT_IN_LDS>(a, lds, (int)blockIdx.x, false);
   }
@@ -454,5 +459,7 @@ hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t str
 hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream) {
   return launch_generic_blocks(a, lds_limit, blocks, stream);
 }
+
+long long cod_workspace_doubles_host(int n, int m) { return cod_workspace_doubles(n, m); }
 
 }  // namespace fccqp

@@ -48,6 +48,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU (metric: 4096)")
     ap.add_argument("--workload", default="W-sat", choices=["W-sat", "W-mix", "W-easy"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fused"])
+    ap.add_argument("--options", default="harness", choices=["harness", "paper"],
+                    help="harness: fcc_qp_test.py:78-83 (headline); paper: fccqp.pdf Table 1 (max_iter=15, eps=1e-4)")
+    ap.add_argument("--warm", action="store_true",
+                    help="secondary mode: time warm-started solves (every step continues from the previous one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     return ap.parse_args()
@@ -132,7 +136,8 @@ def main():
     from fcc_qp_amd import problems as P
     from fcc_qp_amd import sharding as S
 
-    shape, options = P.WALKING, dict(P.HARNESS_OPTIONS)
+    shape = P.WALKING
+    options = dict(P.HARNESS_OPTIONS if args.options == "harness" else P.PAPER_OPTIONS)
     nb = args.batch
     t0 = time.time()
     batch = P.workload(args.workload, nb, shape, seed0=S.rank_seed0(rank, nb))   # instance i: seed 1000 + i
@@ -169,6 +174,8 @@ def main():
         log(f"[bench] parity vs oracle on {k} instances: {parity}")
 
     # ---- timed region ------------------------------------------------------------------------------
+    if args.warm:
+        solver.set_warm_start(True)     # state (x, mu) stays resident; the presolve is skipped (fcc_qp.cpp:159)
     for _ in range(args.warmup):
         step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -210,8 +217,10 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: FCCQP(60,38,12,38) walking-shape OSC QPs, cold start, "
-                            f"rho=5e-5 eps=1e-6/1e-6 max_iter=100 (fcc_qp_test.py:78-83)",
+                "workload": f"{args.workload}: FCCQP(60,38,12,38) walking-shape OSC QPs, "
+                            f"{'warm' if args.warm else 'cold'} start, rho={options['rho']:g} "
+                            f"eps={options['eps_fcone']:g}/{options['eps_bound']:g} max_iter={options['max_iter']} "
+                            f"({'fcc_qp_test.py:78-83' if args.options == 'harness' else 'fccqp.pdf Table 1'})",
                 "batch_per_gpu": nb, "global_batch": nb * world, "parallelism": f"batch-sharded x{world}, no collective",
                 "kernel": {1: "generic", 2: "fused"}[solver.kernel_in_use()],
                 "n_iter_mean": float(n_iter.mean()), "n_iter_at_max_frac": float(np.mean(n_iter == options["max_iter"])),

@@ -115,3 +115,30 @@ def test_torch_tensors_resident_in_hbm_give_the_same_bits():
         F.solve_tensors(bs, *[t.float() for t in tens])
     ptrs = bs.device_pointers()
     assert ptrs["z"] != 0 and ptrs["n_iter"] != 0
+
+
+def test_harness_reproduces_reference_loop_and_series(oracle, tmp_path):
+    """fcc_qp_amd.harness: the reference's load -> warm-started loop -> eight series
+    (/root/reference/fcc_qp_test.py:22-32,44-69,72-89) from a log file in the reference's format."""
+    from fcc_qp_amd import harness as H
+    qps = P.gait_sequence(10, P.WALKING, seed0=9300)
+    path = str(tmp_path / "id_qp_log_walking.npz")
+    P.save_qp_log(path, qps)
+    rep = H.main([path, "--out", str(tmp_path / "r.json")])
+    seq, bat = rep["sequence"], rep["batch"]
+    assert seq["count"] == bat["count"] == 10
+    for key, width in (("u", 10), ("vdot", 22), ("lambda_h", 6), ("lambda_c", 12)):     # slices at :52-56
+        assert np.asarray(seq[key]).shape == (10, width)
+    for key in ("solve_time", "n_iter", "friction_cone_viol", "bounds_viol"):
+        assert len(seq[key]) == 10
+    # the sequential series equals the oracle driven through the same loop
+    o = oracle.OracleFCCQP(60, 38, 12, 38)
+    op = oracle.FCCQPOptions(); op.__dict__.update(P.HARNESS_OPTIONS); o.set_options(op)
+    for i, qp in enumerate(qps):
+        o.set_warm_start(i > 0); o.Solve(**qp); s = o.GetSolution()
+        assert np.max(np.abs(np.asarray(seq["u"][i]) - s.z[22:32])) <= 1e-6 * (1 + np.max(np.abs(s.z)))
+        assert abs(seq["n_iter"][i] - s.details.n_iter) <= 1
+    # the batch series is the cold-start solution of every QP: first entries coincide
+    assert np.allclose(bat["lambda_c"][0], seq["lambda_c"][0], rtol=1e-9, atol=1e-9)
+    import json
+    assert json.load(open(str(tmp_path / "r.json")))["sequence"]["count"] == 10

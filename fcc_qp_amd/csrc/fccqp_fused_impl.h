@@ -423,42 +423,64 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 
   // P0: lower triangle of [[Q + rho I, A^T],[A, 0]] into LDS; Q and A_eq are read front to back,
   // 16 bytes per lane (fcc_qp.cpp:146-150; only Q[i][j], i >= j, is used, like Eigen's Lower LDLT)
+  // Each lane owns one column pair (2l, 2l+1), l = lane & 31, for the whole assembly, so the LDS
+  // column offsets are computed once; lanes 0-31 walk the rows from the top, lanes 32-63 from the
+  // bottom, which pairs a short row of the triangle with a long one (about half the lanes carry
+  // data each trip) and reads only the lower triangle of Q from HBM.
   auto assemble = [&](double rho) {
-    auto put = [&](int i, int j, double v) {  // KKT row i, column j, both < n
-      if (i >= j) M[SH::cbase(j) + i] = v + ((i == j) ? rho : 0.0);
-    };
     if constexpr (n % 2 == 0) {
-      // fully unrolled: the global loads of a whole matrix are in flight together
+      const int half = lane >> 5, l = lane & 31, j0 = 2 * l;
+      const int jc = (j0 < n) ? j0 : 0;
+      const int cb0 = SH::cbase(jc), cb1 = SH::cbase(jc + 1);
+      // all global loads first, unconditionally (idle lanes re-read column pair 0), so that they
+      // are in flight together: a load inside the per-row branch is waited for before the next
+      // row's load is even issued (30 serialised HBM round trips per assembly)
       const d2 *Q2 = reinterpret_cast<const d2 *>(Q);
-      constexpr int QP = n * n / 2, AP = m * n / 2;
+      const d2 *A2 = reinterpret_cast<const d2 *>(A);
+      constexpr int mh = (m + 1) / 2;
+      d2 vq[n / 2], va[mh];
 #pragma unroll
-      for (int t = 0; t < (QP + kWave - 1) / kWave; ++t) {
-        const int p = lane + kWave * t;
-        if (p < QP) {
-          const d2 v = Q2[p];
-          const int e = 2 * p, i = e / n, j = e - i * n;  // n even: a pair never straddles two rows
-          put(i, j, v.x);
-          put(i, j + 1, v.y);
+      for (int it = 0; it < n / 2; ++it) {
+        const int row = half ? (n - 1 - it) : it;
+        vq[it] = Q2[(row * n + jc) >> 1];                 // n even: (row, jc) is 16-byte aligned
+      }
+#pragma unroll
+      for (int it = 0; it < mh; ++it) {
+        const int r = half ? (it + mh) : it;
+        va[it] = A2[(((r < m) ? r : 0) * n + jc) >> 1];
+      }
+#pragma unroll
+      for (int it = 0; it < n / 2; ++it) {
+        const int row = half ? (n - 1 - it) : it;
+        if (j0 < n && j0 <= row) {
+          M[cb0 + row] = vq[it].x + ((row == j0) ? rho : 0.0);
+          if (j0 + 1 <= row) M[cb1 + row] = vq[it].y + ((row == j0 + 1) ? rho : 0.0);
         }
       }
-      const d2 *A2 = reinterpret_cast<const d2 *>(A);
 #pragma unroll
-      for (int t = 0; t < (AP + kWave - 1) / kWave; ++t) {
-        const int p = lane + kWave * t;
-        if (p < AP) {
-          const d2 v = A2[p];
-          const int e = 2 * p, r = e / n, j = e - r * n;
-          M[SH::cbase(j) + n + r] = v.x;
-          M[SH::cbase(j + 1) + n + r] = v.y;
+      for (int it = 0; it < mh; ++it) {
+        const int r = half ? (it + mh) : it;
+        if (j0 < n && r < m) {
+          M[cb0 + n + r] = va[it].x;
+          M[cb1 + n + r] = va[it].y;
         }
       }
     } else {
-      for (int e = lane; e < n * n; e += kWave) { const int i = e / n; put(i, e - i * n, Q[e]); }
+      for (int e = lane; e < n * n; e += kWave) {
+        const int i = e / n, j = e - i * n;
+        if (i >= j) M[SH::cbase(j) + i] = Q[e] + ((i == j) ? rho : 0.0);
+      }
       for (int e = lane; e < m * n; e += kWave) { const int r = e / n; M[SH::cbase(e - r * n) + n + r] = A[e]; }
     }
-    // zero block: rows >= n of columns >= n
-    for (int j = n; j < N; ++j)
-      for (int i = j + lane; i < N; i += kWave) M[SH::cbase(j) + i] = 0.0;
+    // zero block: rows >= n of columns >= n (column j holds rows j..N-1: at most m <= 64 of them)
+    {
+      int cb = SH::cbase(n);
+#pragma unroll 4
+      for (int j = n; j < N; ++j) {
+        if (j + lane < N) M[cb + j + lane] = 0.0;
+        cb += SH::cstep(j);
+      }
+    }
     lds_fence();
   };
 
@@ -474,7 +496,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   int n_iter = 0;
   double x_res_norm = 0.0, lc_res_norm = 0.0;
   // phase stamps (100 MHz): 0 assemble, 1 factor, 2 presolve solve, 3 P3, 4 P4, 5 total
-  long long ph_asm = 0, ph_solve = 0, ph_p3 = 0, ph_p4 = 0;
+  long long ph_asm = 0, ph_asm1 = 0, ph_solve = 0, ph_p3 = 0, ph_p4 = 0;
   const long long t_begin = wall_clock64();
 
   // A cold start needs K twice (presolve on K, ADMM on K + rho I) and the in-place factorisation
@@ -488,6 +510,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     assemble(pass == 0 ? 0.0 : a.rho);  // P1: K (fcc_qp.cpp:146-150,161);  P2: K_rho (fcc_qp.cpp:62-64)
     const long long t0 = wall_clock64();
     ph_asm += t0 - ta;
+    if (pass == 1) ph_asm1 = t0 - ta;
     const bool bad = factor_lds<SH>(M, dvec, lane);
     ticks += wall_clock64() - t0;
     if (pass == 0) {
@@ -660,6 +683,8 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       a.phase_ticks[3 * B + inst] = ph_p3;
       a.phase_ticks[4 * B + inst] = ph_p4;
       a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
+      a.phase_ticks[6 * B + inst] = ph_asm1;
+      a.phase_ticks[7 * B + inst] = t_begin;
     }
   }
 }

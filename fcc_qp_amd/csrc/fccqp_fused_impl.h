@@ -325,54 +325,98 @@ __device__ __forceinline__ bool factor_lds(lds_f64 *M, lds_f64 *dvec, const int 
 }
 
 // x := (L D L^T)^-1 x with M as left by factor_lds; x0/x1 are this lane's rows lane / 64+lane.
+// Column-oriented forward and backward substitution.  The only dependent chain is
+// v_readlane(x_k) -> fma; the L operands of four steps are fetched ahead of it, unconditionally
+// (clamped rows, masked by a select) and through running column offsets, so a step is ~11
+// instructions and no branch.  Rows of idle lanes carry garbage that is never broadcast or stored.
 template <class SH>
 __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, double &x0, double &x1) {
-  constexpr int N = SH::N;
+  constexpr int N = SH::N, U = 4;
+  constexpr int NA = (N < kWave) ? N : kWave;   // columns whose x_k lives in slot 0
   const int row0 = lane, row1 = kWave + lane;
-  const bool ok0 = row0 < N, ok1 = row1 < N;
-  const int cb0 = SH::cbase(ok0 ? row0 : 0), cb1 = SH::cbase(ok1 ? row1 : 0);
-  // forward, unit lower, column oriented; four columns of L are fetched ahead of the dependent
-  // chain (readlane x_k -> fma), which is all that remains on the critical path
-  constexpr int U = 4;
+  const int r0c = (row0 < N) ? row0 : N - 1, r1c = (row1 < N) ? row1 : N - 1;
+  const int cb0 = SH::cbase(r0c), cb1 = SH::cbase(r1c);
+  // ---- forward, unit lower: x_i -= L[i][k] x_k, i > k ----------------------------------------
+  {
+    int cb = SH::cbase(0);
 #pragma nounroll
-  for (int k0 = 0; k0 < N; k0 += U) {
-    double a0[U], a1[U];
+    for (int k0 = 0; k0 < NA; k0 += U) {   // x_k from slot 0; both slots have rows below
+      double a0[U], a1[U];
+      int cbu = cb;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = (k0 + u < N) ? k0 + u : N - 1;
-      const int cb = SH::cbase(k);
-      a0[u] = (ok0 && row0 > k && k0 + u < N) ? M[cb + row0] : 0.0;
-      a1[u] = (ok1 && row1 > k && k0 + u < N) ? M[cb + row1] : 0.0;
+      for (int u = 0; u < U; ++u) {
+        const double l0 = M[cbu + r0c], l1 = M[cbu + r1c];
+        a0[u] = (row0 > k0 + u && k0 + u < NA) ? l0 : 0.0;
+        a1[u] = (k0 + u < NA) ? l1 : 0.0;
+        if (k0 + u + 1 < N) cbu += SH::cstep(k0 + u);
+      }
+      cb = cbu;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double xk = bcast_lane(x0, (k0 + u < NA) ? k0 + u : 0);
+        x0 = fma(-a0[u], xk, x0);
+        if constexpr (N > kWave) x1 = fma(-a1[u], xk, x1);
+      }
     }
+    if constexpr (N > kWave) {
+      cb = SH::cbase(kWave);
+#pragma nounroll
+      for (int k0 = kWave; k0 < N; k0 += U) {   // x_k from slot 1; only slot 1 has rows below
+        double a1[U];
+        int cbu = cb;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = (k0 + u < N) ? k0 + u : N - 1;
-      const int src = k & (kWave - 1);
-      const double xk = (k < kWave) ? bcast_lane(x0, src) : bcast_lane(x1, src);
-      x0 = fma(-a0[u], xk, x0);
-      x1 = fma(-a1[u], xk, x1);
+        for (int u = 0; u < U; ++u) {
+          const double l1 = M[cbu + r1c];
+          a1[u] = (row1 > k0 + u && k0 + u < N) ? l1 : 0.0;
+          if (k0 + u + 1 < N) cbu += SH::cstep(k0 + u);
+        }
+        cb = cbu;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double xk = bcast_lane(x1, (k0 + u < N) ? k0 + u - kWave : 0);
+          x1 = fma(-a1[u], xk, x1);
+        }
+      }
     }
   }
-  // the diagonal slot holds 1/d with Eigen's pseudo-inverse rule folded in
-  x0 = ok0 ? x0 * M[cb0 + row0] : 0.0;
-  x1 = ok1 ? x1 * M[cb1 + row1] : 0.0;
-  // backward with L^T: x_i -= L[k][i] x_k, i < k  (row k of L is a gather along this lane's column)
+  // ---- D^-1: the diagonal slot holds 1/d with Eigen's pseudo-inverse rule folded in -----------
+  x0 *= M[cb0 + r0c];
+  if constexpr (N > kWave) x1 *= M[cb1 + r1c];
+  // ---- backward with L^T: x_i -= L[k][i] x_k, i < k (row k of L: a gather along lane columns) --
+  if constexpr (N > kWave) {
 #pragma nounroll
-  for (int k0 = N - 1; k0 > 0; k0 -= U) {
-    double a0[U], a1[U];
+    for (int k0 = N - 1; k0 >= kWave; k0 -= U) {   // x_k from slot 1; slot 0 rows are all above
+      double a0[U], a1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = (k0 - u >= kWave) ? k0 - u : kWave;
+        const double l0 = M[cb0 + k], l1 = M[cb1 + k];
+        a0[u] = (k0 - u >= kWave) ? l0 : 0.0;
+        a1[u] = (row1 < k && k0 - u >= kWave) ? l1 : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = (k0 - u >= kWave) ? k0 - u : kWave;
+        const double xk = bcast_lane(x1, k - kWave);
+        x0 = fma(-a0[u], xk, x0);
+        x1 = fma(-a1[u], xk, x1);
+      }
+    }
+  }
+#pragma nounroll
+  for (int k0 = NA - 1; k0 >= 1; k0 -= U) {   // x_k from slot 0; only slot 0 has rows above
+    double a0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = (k0 - u > 0) ? k0 - u : 1;
-      a0[u] = (ok0 && row0 < k && k0 - u > 0) ? M[cb0 + k] : 0.0;
-      a1[u] = (ok1 && row1 < k && k0 - u > 0) ? M[cb1 + k] : 0.0;
+      const int k = (k0 - u >= 1) ? k0 - u : 1;
+      const double l0 = M[cb0 + k];
+      a0[u] = (row0 < k && k0 - u >= 1) ? l0 : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = (k0 - u > 0) ? k0 - u : 1;
-      const int src = k & (kWave - 1);
-      const double xk = (k < kWave) ? bcast_lane(x0, src) : bcast_lane(x1, src);
+      const int k = (k0 - u >= 1) ? k0 - u : 1;
+      const double xk = bcast_lane(x0, k);
       x0 = fma(-a0[u], xk, x0);
-      x1 = fma(-a1[u], xk, x1);
     }
   }
 }

@@ -257,13 +257,16 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
   bool bad_any = false;
   double dmine = 1.0, rmine = 0.0;
   const int ncol = (N - c0 < P) ? N - c0 : P;   // columns that exist (the last panel may be short)
+  // the pivot of column k+1 is broadcast and inverted as soon as column k+1 has received step k's
+  // update (the first one issued), so the reciprocal chain of the next step hides under the rest
+  // of this step's FMAs
+  double d = bcast_lane(USE0 ? T0[0] : T1[0], lane0);
+  double rinv = fast_rcp(d);
 #pragma unroll
   for (int k = 0; k < P; ++k) {
-    const double d = bcast_lane(USE0 ? T0[k] : T1[k], lane0 + k);
     // zero, infinite or NaN pivot (class mask: sNaN|qNaN|-inf|-0|+0|+inf); columns past N in a
     // short last panel hold garbage that is computed on (no branch) but neither judged nor stored
     bad_any |= (k < ncol) & __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
-    const double rinv = fast_rcp(d);
     dmine = (rel == k) ? d : dmine;
     rmine = (rel == k) ? ((fabs(d) > DBL_MIN) ? rinv : 0.0) : rmine;
     const double a0 = T0[k], a1 = T1[k];
@@ -276,6 +279,7 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
     // asm keeps this order -- left alone the scheduler separates the two FMAs of a scalar and
     // spills every scalar to a VGPR lane (v_writelane + s_nop) to read it back later.
     double lcur = (k + 1 < P) ? bcast_lane(lsrc, lane0 + k + 1) : 0.0;
+    double dn = d, rn = rinv;
 #pragma unroll
     for (int jj = k + 1; jj < P; ++jj) {
       double lnext = (jj + 1 < P) ? bcast_lane(lsrc, lane0 + jj + 1) : 0.0;
@@ -283,8 +287,13 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
       T1[jj] = fma(-a1, lcur, T1[jj]);
       if constexpr (USE0) asm volatile("" : "+v"(T0[jj]), "+v"(T1[jj]), "+s"(lnext));
       else asm volatile("" : "+v"(T1[jj]), "+s"(lnext));
+      if (jj == k + 1) {  // column k+1 is final: look ahead
+        dn = bcast_lane(USE0 ? T0[jj] : T1[jj], lane0 + jj);
+        rn = fast_rcp(dn);
+      }
       lcur = lnext;
     }
+    d = dn; rinv = rn;
   }
   // (d) write the panel back: rows below the diagonal block take all 16 columns ...
   if constexpr (USE0) {

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       const int half = lane >> 5, l = lane & 31, j0 = 2 * l;
       const int jc = (j0 < n) ? j0 : 0;
       const int cb0 = SH::cbase(jc), cb1 = SH::cbase(jc + 1);
-      // all global loads first, unconditionally (idle lanes re-read column pair 0), so that they
+      // all global loads first, unconditionally (idle lanes re-read a pair another lane needs), so that they
       // are in flight together: a load inside the per-row branch is waited for before the next
       // row's load is even issued (30 serialised HBM round trips per assembly)
       const d2 *Q2 = reinterpret_cast<const d2 *>(Q);
@@ -495,7 +495,9 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 #pragma unroll
       for (int it = 0; it < n / 2; ++it) {
         const int row = half ? (n - 1 - it) : it;
-        vq[it] = Q2[(row * n + jc) >> 1];                 // n even: (row, jc) is 16-byte aligned
+        // lanes above the diagonal re-read the row's first pair (same cache line): only the lower
+        // triangle of Q comes from HBM.  n even: (row, j) is 16-byte aligned for even j
+        vq[it] = Q2[(row * n + ((j0 < n && j0 <= row) ? j0 : 0)) >> 1];
       }
 #pragma unroll
       for (int it = 0; it < mh; ++it) {

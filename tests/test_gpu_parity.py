@@ -47,6 +47,8 @@ def test_walking_workloads_match_oracle(oracle, wl, kernel):
     P.PAPER_OPTIONS,
     dict(max_iter=1, rho=5e-5, eps_fcone=1e-6, eps_bound=1e-6),
     dict(max_iter=1000, rho=1e-6, eps_fcone=1e-3, eps_bound=1e-6),   # reference defaults (fcc_qp.hpp:30-35)
+    dict(max_iter=0, rho=5e-5, eps_fcone=1e-6, eps_bound=1e-6),      # loop never runs: z = x0, status kMaxIterations
+    dict(max_iter=3, rho=10.0, eps_fcone=1e9, eps_bound=1e9),        # huge eps: exits at iteration 0
 ])
 def test_option_sets_match_oracle(oracle, options, kernel):
     B = P.workload("W-mix", 48, P.WALKING)

@@ -556,8 +556,8 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 
   // A cold start needs K twice (presolve on K, ADMM on K + rho I) and the in-place factorisation
   // destroys it; the second assembly reads Q and A_eq again (L2 / Infinity-Cache hits mostly).
-  // A 39 KB per-lane register copy was tried: the allocator parks it in scratch, which costs more
-  // memory traffic than the re-read.
+  // A per-lane register copy of the 39 KB image was tried (twice): the allocator parks it in
+  // scratch instead of AGPRs, which costs more memory traffic than the re-read.
 #pragma nounroll
   for (int pass = cold ? 0 : 1; pass < 2; ++pass) {
     if (pass == 1 && equality_constrained) break;

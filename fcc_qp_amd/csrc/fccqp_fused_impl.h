@@ -643,6 +643,9 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
           constexpr int c = decltype(cc)::value;
           if constexpr (c + 1 < NCHUNK) load(std::integral_constant<int, c + 1>{});
           __builtin_amdgcn_sched_barrier(0);
+          // one wait per chunk instead of one per FMA pair (each s_waitcnt is an issue slot)
+          constexpr int nxt = (c + 1 < NCHUNK) ? (((c + 2) * CH <= NP) ? CH : NP - (c + 1) * CH) : 0;
+          __builtin_amdgcn_s_waitcnt(0xC07F | (nxt << 8));
           static_for<0, CH>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int j = 2 * (c * CH + i);

@@ -23,11 +23,15 @@
 #include "fccqp_cod_impl.h"
 
 #include <cfloat>
+#include <type_traits>
 
 namespace fccqp {
 namespace {
 
 constexpr int kWave = 64;
+// explicit LDS address space: a generic `double *` that may point to LDS or global memory compiles
+// to flat_load / flat_store, whose latency is several times that of ds_read / ds_write
+using lds_f64 = __attribute__((address_space(3))) double;
 
 __device__ __forceinline__ void wave_sync() {
   // Single-wave workgroup: LDS/global accesses of one wave execute in program order; the fence
@@ -70,8 +74,8 @@ __device__ __forceinline__ int col_base(int j, int N) { return j * N - (j * (j -
 
 // Unpivoted LDL^T in place (right-looking), natural order.  Returns true if a pivot was zero or
 // not finite (the situation in which Eigen's info() != Success can arise, fcc_qp.cpp:164).
-template <int SLOTS>
-__device__ bool ldlt_factor(double *M, int N, int lane) {
+template <int SLOTS, class MP>
+__device__ bool ldlt_factor(MP M, int N, int lane) {
   bool bad_any = false;
   for (int k = 0; k < N; ++k) {
     const int ck = col_base(k, N);
@@ -107,43 +111,76 @@ __device__ bool ldlt_factor(double *M, int N, int lane) {
 }
 
 // x := (L D L^T)^-1 x with Eigen's pseudo-inverse rule on D (|d| > DBL_MIN else 0).
-// x is lane-distributed: lane owns entries lane + 64 t.
-template <int SLOTS>
-__device__ void ldlt_solve(const double *M, int N, int lane, double (&x)[SLOTS]) {
-  // forward, unit lower, column oriented
+// x is lane-distributed: lane owns entries lane + 64 t.  Column-oriented substitution; the only
+// dependent chain is v_readlane(x_k) -> fma: the L operands of four steps are fetched ahead of
+// it, unconditionally (clamped rows, masked by a select) and through running column offsets.
+template <int SLOTS, class MP>
+__device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
+  constexpr int U = 4;
+  int rowc[SLOTS], cbl[SLOTS];
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const int i = lane + kWave * t;
+    rowc[t] = (i < N) ? i : N - 1;          // clamped: idle rows read valid memory, results unused
+    cbl[t] = col_base(rowc[t], N);
+  }
+  // ---- forward, unit lower: x_i -= L[i][k] x_k, i > k; x_k lives in slot s, lane k - 64 s -------
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
-    for (int kk = 0; kk < kWave; ++kk) {
-      const int k = s * kWave + kk;
-      if (k >= N) break;
-      const double xk = lane_bcast(x[s], kk);
-      const int ck = col_base(k, N);
+    const int kend = (N - s * kWave < kWave) ? N - s * kWave : kWave;   // columns in this slot
+    if (kend <= 0) break;
+    int cb = col_base(s * kWave, N);
+    for (int kk0 = 0; kk0 < kend; kk0 += U) {
+      double a[U][SLOTS];
+      int cbu = cb;
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int i = lane + kWave * t;
-        if (i > k && i < N) x[t] -= M[ck + i] * xk;
+      for (int u = 0; u < U; ++u) {
+        const int k = s * kWave + kk0 + u;
+        const bool live = kk0 + u < kend;
+#pragma unroll
+        for (int t = s; t < SLOTS; ++t) {
+          const double l = M[cbu + rowc[t]];
+          a[u][t] = (live && lane + kWave * t > k && lane + kWave * t < N) ? l : 0.0;
+        }
+        if (k + 1 < N) cbu += N - k - 1;     // col_base(k + 1) - col_base(k)
+      }
+      cb = cbu;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double xk = lane_bcast(x[s], (kk0 + u < kend) ? kk0 + u : 0);
+#pragma unroll
+        for (int t = s; t < SLOTS; ++t) x[t] = fma(-a[u][t], xk, x[t]);
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < SLOTS; ++t) {
     const int i = lane + kWave * t;
-    if (i < N) {
-      const double d = M[col_base(i, N) + i];
-      x[t] = (fabs(d) > DBL_MIN) ? x[t] / d : 0.0;
-    }
+    const double d = M[cbl[t] + rowc[t]];
+    x[t] = (i < N && fabs(d) > DBL_MIN) ? x[t] / d : 0.0;
   }
-  // backward with L^T: x_i -= L[k][i] * x_k for i < k
+  // ---- backward with L^T: x_i -= L[k][i] x_k, i < k (row k of L: a gather along lane columns) --
 #pragma unroll
   for (int s = SLOTS - 1; s >= 0; --s) {
-    for (int kk = kWave - 1; kk >= 0; --kk) {
-      const int k = s * kWave + kk;
-      if (k >= N) continue;
-      const double xk = lane_bcast(x[s], kk);
+    const int kend = (N - s * kWave < kWave) ? N - s * kWave : kWave;
+    if (kend <= 0) continue;
+    for (int kk0 = kend - 1; kk0 >= 0; kk0 -= U) {
+      double a[U][SLOTS];
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int i = lane + kWave * t;
-        if (i < k) x[t] -= M[col_base(i, N) + k] * xk;
+      for (int u = 0; u < U; ++u) {
+        const bool live = kk0 - u >= 0;
+        const int k = s * kWave + (live ? kk0 - u : 0);
+#pragma unroll
+        for (int t = 0; t <= s; ++t) {
+          const double l = M[cbl[t] + k];
+          a[u][t] = (live && lane + kWave * t < k) ? l : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double xk = lane_bcast(x[s], (kk0 - u >= 0) ? kk0 - u : 0);
+#pragma unroll
+        for (int t = 0; t <= s; ++t) x[t] = fma(-a[u][t], xk, x[t]);
       }
     }
   }
@@ -174,8 +211,12 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   const int n = a.n, m = a.m, nc = a.nc, s0 = a.s, N = n + m;
   const int npack = (N * (N + 1)) / 2;
 
-  double *M = MAT_IN_LDS ? lds : (a.workspace + (long long)blockIdx.x * a.workspace_stride);
-  double *cone_buf = MAT_IN_LDS ? (lds + npack) : lds;  // nc doubles of cross-lane scratch
+  // matrix: LDS (ds_* instructions) or the per-block global workspace (global_* instructions)
+  using MP = std::conditional_t<MAT_IN_LDS, lds_f64 *, double *>;
+  MP M;
+  if constexpr (MAT_IN_LDS) M = (lds_f64 *)lds;
+  else M = a.workspace + (long long)blockIdx.x * a.workspace_stride;
+  lds_f64 *cone_buf = (lds_f64 *)(MAT_IN_LDS ? (lds + npack) : lds);  // nc doubles of cross-lane scratch
 
   const double *Q = a.Q + (size_t)inst * n * n;
   const double *A = a.A + (size_t)inst * m * n;
@@ -238,7 +279,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     flags |= kFlagPresolveRan;
     assemble(0.0);
     const long long t0 = wall_clock64();
-    const bool bad = ldlt_factor<SLOTS>(M, N, lane);
+    const bool bad = ldlt_factor<SLOTS, MP>(M, N, lane);
     ticks += wall_clock64() - t0;
     if (bad) {
       flags |= kFlagPresolveNumerical;
@@ -258,7 +299,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
       const int i = lane + kWave * t;
       r[t] = (i < n) ? -vb[t] : vtail[t];  // [-b; b_eq]  (:149-150)
     }
-    ldlt_solve<SLOTS>(M, N, lane, r);
+    ldlt_solve<SLOTS, MP>(M, N, lane, r);
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) {
       const int i = lane + kWave * t;
@@ -273,7 +314,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   if (!equality_constrained) {
     assemble(a.rho);                                   // :62-64
     const long long t0 = wall_clock64();
-    const bool bad = ldlt_factor<SLOTS>(M, N, lane);   // :68 (info() unchecked in the reference)
+    const bool bad = ldlt_factor<SLOTS, MP>(M, N, lane);   // :68 (info() unchecked in the reference)
     ticks += wall_clock64() - t0;
     if (bad) flags |= kFlagAdmmNumerical;
 
@@ -291,7 +332,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
         if (is_cone[t]) q = -a.rho * (lcbar[t] - mulc[t]);          // :82 overwrites the segment
         r[t] = (i < n) ? -(vb[t] + q) : vtail[t];                   // :83
       }
-      ldlt_solve<SLOTS>(M, N, lane, r);                             // :86
+      ldlt_solve<SLOTS, MP>(M, N, lane, r);                             // :86
 #pragma unroll
       for (int t = 0; t < SLOTS; ++t) {
         const int i = lane + kWave * t;

@@ -556,8 +556,11 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 
   // A cold start needs K twice (presolve on K, ADMM on K + rho I) and the in-place factorisation
   // destroys it; the second assembly reads Q and A_eq again (L2 / Infinity-Cache hits mostly).
-  // A per-lane register copy of the 39 KB image was tried (twice): the allocator parks it in
-  // scratch instead of AGPRs, which costs more memory traffic than the re-read.
+  // Keeping the image on-chip across the presolve was tried four ways (plain register array,
+  // AGPR-class inline-asm values, a mix of both, hand-partitioned AGPRs under amdgpu_num_vgpr):
+  // the allocator either parks ~30 KB per wave in scratch -- more traffic than the re-read -- or
+  // ignores the partition.  Measured with a (wrong-result) hand-partitioned build: 0.91x
+  // algorithmic bytes instead of 1.43x and -6 us per QP; needs an assembly-level kernel.
 #pragma nounroll
   for (int pass = cold ? 0 : 1; pass < 2; ++pass) {
     if (pass == 1 && equality_constrained) break;

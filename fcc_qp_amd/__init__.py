@@ -30,7 +30,7 @@ try:
 except ImportError as exc:  # fail loudly: the HIP extension IS the product
     raise ImportError(
         "fcc_qp_amd: the native extension (fcc_qp_amd/libfccqp_hip.so + fcc_qp_solver*.so) is not "
-        "built or cannot be loaded. Run `python -m fcc_qp_amd.build` (needs hipcc, gfx950). "
+        "built or cannot be loaded. Run `python fcc_qp_amd/build.py` or __graft_entry__.build() (needs hipcc, gfx950). "
         f"There is no CPU fallback. Original error: {exc}") from exc
 
 from . import problems  # noqa: E402,F401

@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # A fresh clone has no built artefacts (they are git-ignored): build them once, in tree, exactly
+    # as __graft_entry__.build() does.  hipcc cross-compiles gfx950 without a GPU (a few minutes).
+    lib = os.path.join(ROOT, "fcc_qp_amd", "libfccqp_hip.so")
+    mods = [f for f in os.listdir(os.path.join(ROOT, "fcc_qp_amd")) if f.startswith("fcc_qp_solver") and f.endswith(".so")]
+    if not os.path.exists(lib) or not mods:
+        import importlib.util                       # the package itself refuses to import unbuilt
+        spec = importlib.util.spec_from_file_location("fcc_qp_amd_build", os.path.join(ROOT, "fcc_qp_amd", "build.py"))
+        _build = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_build)
+        _build.build_all()
 
 
 @pytest.fixture(scope="session")

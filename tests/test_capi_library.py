@@ -10,7 +10,7 @@ from tests import capi as C
 
 
 def test_library_is_built_in_tree():
-    assert os.path.exists(C.LIB_PATH), "run `python -m fcc_qp_amd.build` (or __graft_entry__.build())"
+    assert os.path.exists(C.LIB_PATH), "run `python fcc_qp_amd/build.py` (or __graft_entry__.build())"
 
 
 def test_exports_every_declared_function():

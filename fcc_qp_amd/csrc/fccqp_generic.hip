@@ -117,70 +117,92 @@ __device__ bool ldlt_factor(MP M, int N, int lane) {
 template <int SLOTS, class MP>
 __device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
   constexpr int U = 4;
-  int rowc[SLOTS], cbl[SLOTS];
+  // per-slot row indices: rlo = row or -1 for an idle lane (never "> k"), rhi = row or INT_MAX
+  // (never "< k"); rowc = clamped row for in-bounds operand reads
+  int rowc[SLOTS], cbl[SLOTS], rlo[SLOTS], rhi[SLOTS];
 #pragma unroll
   for (int t = 0; t < SLOTS; ++t) {
     const int i = lane + kWave * t;
-    rowc[t] = (i < N) ? i : N - 1;          // clamped: idle rows read valid memory, results unused
+    rowc[t] = (i < N) ? i : N - 1;
+    rlo[t] = (i < N) ? i : -1;
+    rhi[t] = (i < N) ? i : 0x7fffffff;
     cbl[t] = col_base(rowc[t], N);
   }
   // ---- forward, unit lower: x_i -= L[i][k] x_k, i > k; x_k lives in slot s, lane k - 64 s -------
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int kend = (N - s * kWave < kWave) ? N - s * kWave : kWave;   // columns in this slot
-    if (kend <= 0) break;
-    int cb = col_base(s * kWave, N);
-    for (int kk0 = 0; kk0 < kend; kk0 += U) {
-      double a[U][SLOTS];
-      int cbu = cb;
+    if (kend > 0) {
+      int cb = col_base(s * kWave, N);
+      const int kfull = kend & ~(U - 1);
+      for (int kk0 = 0; kk0 < kfull; kk0 += U) {   // groups of U columns, operands fetched ahead
+        double a[U][SLOTS];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = s * kWave + kk0 + u;
-        const bool live = kk0 + u < kend;
+        for (int u = 0; u < U; ++u) {
+          const int k = s * kWave + kk0 + u;
+#pragma unroll
+          for (int t = s; t < SLOTS; ++t) {
+            const double l = M[cb + rowc[t]];
+            a[u][t] = (rlo[t] > k) ? l : 0.0;
+          }
+          cb += N - k - 1;                         // col_base(k + 1) - col_base(k)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double xk = lane_bcast(x[s], kk0 + u);
+#pragma unroll
+          for (int t = s; t < SLOTS; ++t) x[t] = fma(-a[u][t], xk, x[t]);
+        }
+      }
+      for (int kk = kfull; kk < kend; ++kk) {      // remainder, one column at a time
+        const int k = s * kWave + kk;
+        const double xk = lane_bcast(x[s], kk);
 #pragma unroll
         for (int t = s; t < SLOTS; ++t) {
-          const double l = M[cbu + rowc[t]];
-          a[u][t] = (live && lane + kWave * t > k && lane + kWave * t < N) ? l : 0.0;
+          const double l = M[cb + rowc[t]];
+          x[t] = fma(-((rlo[t] > k) ? l : 0.0), xk, x[t]);
         }
-        if (k + 1 < N) cbu += N - k - 1;     // col_base(k + 1) - col_base(k)
-      }
-      cb = cbu;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double xk = lane_bcast(x[s], (kk0 + u < kend) ? kk0 + u : 0);
-#pragma unroll
-        for (int t = s; t < SLOTS; ++t) x[t] = fma(-a[u][t], xk, x[t]);
+        cb += N - k - 1;
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < SLOTS; ++t) {
-    const int i = lane + kWave * t;
     const double d = M[cbl[t] + rowc[t]];
-    x[t] = (i < N && fabs(d) > DBL_MIN) ? x[t] / d : 0.0;
+    x[t] = (rlo[t] >= 0 && fabs(d) > DBL_MIN) ? x[t] / d : 0.0;
   }
   // ---- backward with L^T: x_i -= L[k][i] x_k, i < k (row k of L: a gather along lane columns) --
 #pragma unroll
   for (int s = SLOTS - 1; s >= 0; --s) {
     const int kend = (N - s * kWave < kWave) ? N - s * kWave : kWave;
-    if (kend <= 0) continue;
-    for (int kk0 = kend - 1; kk0 >= 0; kk0 -= U) {
-      double a[U][SLOTS];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool live = kk0 - u >= 0;
-        const int k = s * kWave + (live ? kk0 - u : 0);
+    if (kend > 0) {
+      const int rem = kend & (U - 1);
+      for (int kk = kend - 1; kk >= kend - rem; --kk) {   // remainder first (highest columns)
+        const int k = s * kWave + kk;
+        const double xk = lane_bcast(x[s], kk);
 #pragma unroll
         for (int t = 0; t <= s; ++t) {
           const double l = M[cbl[t] + k];
-          a[u][t] = (live && lane + kWave * t < k) ? l : 0.0;
+          x[t] = fma(-((rhi[t] < k) ? l : 0.0), xk, x[t]);
         }
       }
+      for (int kk0 = kend - rem - 1; kk0 >= 0; kk0 -= U) {
+        double a[U][SLOTS];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double xk = lane_bcast(x[s], (kk0 - u >= 0) ? kk0 - u : 0);
+        for (int u = 0; u < U; ++u) {
+          const int k = s * kWave + kk0 - u;
 #pragma unroll
-        for (int t = 0; t <= s; ++t) x[t] = fma(-a[u][t], xk, x[t]);
+          for (int t = 0; t <= s; ++t) {
+            const double l = M[cbl[t] + k];
+            a[u][t] = (rhi[t] < k) ? l : 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double xk = lane_bcast(x[s], kk0 - u);
+#pragma unroll
+          for (int t = 0; t <= s; ++t) x[t] = fma(-a[u][t], xk, x[t]);
+        }
       }
     }
   }

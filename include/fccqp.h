@@ -72,7 +72,8 @@ enum {
 enum {
   FCCQP_KERNEL_AUTO = 0,     /* specialised kernel when the shape has one, else generic          */
   FCCQP_KERNEL_GENERIC = 1,  /* any shape: LDS/global-resident KKT, triangular solves per iter   */
-  FCCQP_KERNEL_FUSED = 2     /* shape-specialised register-resident kernel                       */
+  FCCQP_KERNEL_FUSED = 2     /* shape-specialised: panel LDL^T in LDS + one block solve for
+                                G = (K_rho^-1)[0:n,0:n], mat-vec ADMM iterations (walking shape)  */
 };
 
 /* reference: struct FCCQPOptions, src/fcc_qp.hpp:30-35 (same defaults) */

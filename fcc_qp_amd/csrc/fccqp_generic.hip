@@ -9,13 +9,14 @@
 // Design (MI355X): a workgroup is one wavefront, so no barrier is ever needed.  The KKT matrix
 // [[Q(+rho I), A^T],[A, 0]] is assembled once into LDS as a packed lower triangle
 // (column-major, column j holds rows j..N-1 contiguously, so a lane-per-row sweep of a column is
-// bank-conflict free) and factorised in place by an unpivoted LDL^T in natural order.  The matrix
+// bank-conflict free) and factorised in place by an unpivoted LDL^T in natural order (16-column
+// left-looking panels, ldlt_panel below).  The matrix
 // is symmetric quasi-definite for rho > 0 / Q > 0, so every symmetric pivot order exists; the
 // reference's Eigen LDLT pivots by the largest remaining diagonal entry, which only reorders the
 // same block elimination -- results agree to ~1e-13 relative (tests/test_numerics_choice.py).
 // All vectors (rhs, x, duals, bounds) live in registers, lane i owning entries i, i+64, ...
-// Shapes whose packed KKT exceeds the LDS budget spill the matrix to a per-block global
-// workspace (same code path through a generic pointer).
+// Shapes whose packed KKT exceeds the LDS budget (N > 198) keep the matrix in a per-block global
+// workspace and use the unblocked factorisation.
 //
 // This is the any-shape path and the first correct HIP path; the shape-specialised kernel in
 // fccqp_fused.hip is the fast one.
@@ -69,13 +70,164 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// packed lower, column-major: element (i,j), i >= j, at col_base(j) + i  (col_base includes -j)
-__device__ __forceinline__ int col_base(int j, int N) { return j * N - (j * (j - 1)) / 2 - j; }
+// Packed lower triangle, column-major: element (i,j), i >= j, at col_base(j) + i.  Column starts
+// are padded so that col_base(j) is even: an element's address parity is its row parity and a
+// ds_read_b128 of rows (2r, 2r+1) of any column is 16-byte aligned.
+__host__ __device__ __forceinline__ int col_start(int j, int N) {
+  return j * N - (j * (j - 1)) / 2 + ((N & 1) ? j / 2 : (j + 1) / 2);
+}
+__host__ __device__ __forceinline__ int col_base(int j, int N) { return col_start(j, N) - j; }
+// col_base(j + 1) - col_base(j)
+__device__ __forceinline__ int col_step(int j, int N) { return N - j - 1 + (((j ^ N) & 1) ? 0 : 1); }
+__host__ __device__ __forceinline__ int packed_doubles(int N) { return (col_start(N, N) + 1) & ~1; }
 
-// Unpivoted LDL^T in place (right-looking), natural order.  Returns true if a pivot was zero or
-// not finite (the situation in which Eigen's info() != Success can arise, fcc_qp.cpp:164).
-template <int SLOTS, class MP>
-__device__ bool ldlt_factor(MP M, int N, int lane) {
+__device__ __forceinline__ double fast_rcp(double d) {   // <= 1 ulp from the rounded quotient
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+constexpr int kPanel = 16;
+using d2 = double __attribute__((ext_vector_type(2)));
+using lds_d2 = __attribute__((address_space(3))) d2;
+
+// One 16-column panel of the left-looking LDL^T (matrix in LDS), columns c0..c0+15, for a wave
+// whose lanes own rows lane + 64 t.  SD = c0 / 64 is the register slot the panel's diagonal block
+// lives in; slots above it hold rows above the panel and are not touched.  Same scheme as the
+// shape-specialised kernel (fccqp_fused_impl.h factor_panel): (a) panel columns into registers,
+// (b) subtract the contribution of every earlier column -- per column 8 broadcast ds_read_b128
+// of L[c0..c0+15][q] + one private read per slot, software-pipelined two columns per trip,
+// (c) factorise the 16x16 diagonal block and the rows below it with the multipliers read out of
+// the owner lanes (v_readlane), (d) one write-back.  The diagonal slot keeps d (the solve applies
+// Eigen's pseudo-inverse rule).  Returns true on a zero / non-finite pivot.
+template <int SLOTS, int SD>
+__device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int lane, const int c0) {
+  constexpr int P = kPanel, NT = SLOTS - SD;
+  int rc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int row = lane + kWave * (SD + t);
+    rc[t] = (row < N) ? row : N - 1;               // clamped: in-bounds reads for idle lanes
+  }
+  double T[NT][P];
+#pragma unroll
+  for (int jj = 0; jj < P; ++jj) {
+    const int j = (c0 + jj < N) ? c0 + jj : N - 1;
+    const int cb = col_base(j, N);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) T[t][jj] = M[cb + rc[t]];   // rows above the diagonal: garbage, never stored
+  }
+  struct Ops { d2 w[P / 2]; double u[NT]; double dq; };
+  auto fetch = [&](const int cb, const int q, Ops &o) {
+    const lds_d2 *bc = reinterpret_cast<const lds_d2 *>(M + cb + c0);
+#pragma unroll
+    for (int t = 0; t < P / 2; ++t) o.w[t] = bc[t];          // may run past row N-1 in the last panel: unused
+    o.dq = M[cb + q];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) o.u[t] = M[cb + rc[t]];
+  };
+  auto apply = [&](const Ops &o) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const double u = o.u[t] * o.dq;
+#pragma unroll
+      for (int h = 0; h < P / 2; ++h) {
+        T[t][2 * h] = fma(-u, o.w[h].x, T[t][2 * h]);
+        T[t][2 * h + 1] = fma(-u, o.w[h].y, T[t][2 * h + 1]);
+      }
+    }
+  };
+  if (c0 > 0) {                                              // c0 is a multiple of 16: q, q+1 < c0
+    Ops oa, ob;
+    int cb = col_base(0, N);
+    fetch(cb, 0, oa);
+#pragma nounroll
+    for (int q = 0; q < c0; q += 2) {
+      cb += col_step(q, N);
+      fetch(cb, q + 1, ob);
+      apply(oa);
+      cb += col_step(q + 1, N);
+      fetch(cb, (q + 2 < N) ? q + 2 : q + 1, oa);            // one past the end on the last trip: unused
+      apply(ob);
+    }
+  }
+  const int lane0 = c0 & (kWave - 1);
+  const int rel = lane - lane0;
+  const int ncol = (N - c0 < P) ? N - c0 : P;
+  bool bad_any = false;
+  double dmine = 1.0;
+  double d = lane_bcast(T[0][0], lane0);
+  double rinv = fast_rcp(d);
+#pragma unroll
+  for (int k = 0; k < P; ++k) {
+    // zero, infinite or NaN pivot; columns past N in a short last panel hold garbage that is
+    // computed on (no branch) but neither judged nor stored
+    bad_any |= (k < ncol) & __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
+    dmine = (rel == k) ? d : dmine;
+    double av[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { av[t] = T[t][k]; T[t][k] = av[t] * rinv; }
+    const double lsrc = T[0][k];
+    double lcur = (k + 1 < P) ? lane_bcast(lsrc, lane0 + k + 1) : 0.0;
+    double dn = d, rn = rinv;
+#pragma unroll
+    for (int jj = k + 1; jj < P; ++jj) {
+      double lnext = (jj + 1 < P) ? lane_bcast(lsrc, lane0 + jj + 1) : 0.0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) T[t][jj] = fma(-av[t], lcur, T[t][jj]);
+      // keeps each scalar next to its FMAs (otherwise they are spilled to VGPR lanes)
+      asm volatile("" : "+v"(T[0][jj]), "+s"(lnext));
+      if (jj == k + 1) {
+        dn = lane_bcast(T[0][jj], lane0 + jj);
+        rn = fast_rcp(dn);
+      }
+      lcur = lnext;
+    }
+    d = dn; rinv = rn;
+  }
+  // write-back: rows below the diagonal block take all columns, the block's own rows what lies
+  // strictly below the diagonal plus d
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int row = lane + kWave * (SD + t);
+    if (row >= c0 + P && row < N) {
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        if (k < ncol) M[col_base(c0 + k, N) + row] = T[t][k];
+    }
+  }
+  if (rel >= 0 && rel < ncol) {
+    const int rowd = lane + kWave * SD;
+#pragma unroll
+    for (int k = 0; k < P - 1; ++k)
+      if (rel > k) M[col_base(c0 + k, N) + rowd] = T[0][k];
+    M[col_base(rowd, N) + rowd] = dmine;
+  }
+  wave_sync();
+  return bad_any;
+}
+
+template <int SLOTS>
+__device__ bool ldlt_factor(lds_f64 *M, int N, int lane) {
+  static_assert(SLOTS <= 4, "a matrix that fits in LDS has N <= 256");
+  bool bad = false;
+#pragma nounroll
+  for (int c0 = 0; c0 < N; c0 += kPanel) {
+    const int sd = c0 >> 6;
+    if (sd == 0) bad |= ldlt_panel<SLOTS, 0>(M, N, lane, c0);
+    if constexpr (SLOTS > 1) { if (sd == 1) bad |= ldlt_panel<SLOTS, 1>(M, N, lane, c0); }
+    if constexpr (SLOTS > 2) { if (sd == 2) bad |= ldlt_panel<SLOTS, 2>(M, N, lane, c0); }
+    if constexpr (SLOTS > 3) { if (sd == 3) bad |= ldlt_panel<SLOTS, 3>(M, N, lane, c0); }
+  }
+  return bad;
+}
+
+// Unpivoted LDL^T in place (right-looking), natural order: the variant for matrices that do not
+// fit in LDS (global workspace).  Returns true if a pivot was zero or not finite (the situation
+// in which Eigen's info() != Success can arise, fcc_qp.cpp:164).
+template <int SLOTS>
+__device__ bool ldlt_factor(double *M, int N, int lane) {
   bool bad_any = false;
   for (int k = 0; k < N; ++k) {
     const int ck = col_base(k, N);
@@ -145,7 +297,7 @@ __device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
             const double l = M[cb + rowc[t]];
             a[u][t] = (rlo[t] > k) ? l : 0.0;
           }
-          cb += N - k - 1;                         // col_base(k + 1) - col_base(k)
+          cb += col_step(k, N);                    // col_base(k + 1) - col_base(k)
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -162,7 +314,7 @@ __device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
           const double l = M[cb + rowc[t]];
           x[t] = fma(-((rlo[t] > k) ? l : 0.0), xk, x[t]);
         }
-        cb += N - k - 1;
+        cb += col_step(k, N);
       }
     }
   }
@@ -231,7 +383,7 @@ template <int SLOTS, bool MAT_IN_LDS>
 __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst, const bool x0_given) {
   const int lane = threadIdx.x;
   const int n = a.n, m = a.m, nc = a.nc, s0 = a.s, N = n + m;
-  const int npack = (N * (N + 1)) / 2;
+  const int npack = packed_doubles(N);
 
   // matrix: LDS (ds_* instructions) or the per-block global workspace (global_* instructions)
   using MP = std::conditional_t<MAT_IN_LDS, lds_f64 *, double *>;
@@ -280,16 +432,38 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   long long ticks = 0;
 
   // ---- assemble the packed lower KKT (fcc_qp.cpp:146-150) --------------------------------
+  // Row-wise: lanes run along a row of Q (then A), so global reads are coalesced, and the loads of
+  // eight rows are issued before the first LDS store.  Only the lower triangle of Q is kept (what
+  // Eigen's LDLT reads).  Loads are unconditional on clamped addresses; the mask only gates stores.
   auto assemble = [&](double rho) {
-    for (int j = 0; j < N; ++j) {
-      const int cj = col_base(j, N);
-      for (int i = j + lane; i < N; i += kWave) {
-        double v;
-        if (i < n) v = Q[(size_t)i * n + j] + ((i == j) ? rho : 0.0);
-        else if (j < n) v = A[(size_t)(i - n) * n + j];
-        else v = 0.0;
-        M[cj + i] = v;
+    constexpr int R = 8;
+    const int jc_hi = (n > 0) ? n - 1 : 0;
+    if (n > 0) {
+      for (int i0 = 0; i0 < N; i0 += R) {
+        const int ilast = (i0 + R - 1 < N) ? i0 + R - 1 : N - 1;
+        const int jend = (ilast < n) ? ilast + 1 : n;          // columns needed by this row group
+        for (int j0 = 0; j0 < jend; j0 += kWave) {
+          const int j = j0 + lane;
+          const int jc = (j < jc_hi) ? j : jc_hi;
+          double v[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int i = (i0 + r < N) ? i0 + r : N - 1;
+            const double *src = (i < n) ? Q + (size_t)i * n : A + (size_t)(i - n) * n;
+            v[r] = src[jc];
+          }
+          const int cj = col_base(jc, N);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int i = i0 + r;
+            if (i < N && j < n && j <= i) M[cj + i] = v[r] + ((i == j) ? rho : 0.0);
+          }
+        }
       }
+    }
+    for (int j = n; j < N; ++j) {                              // zero block (rows and columns >= n)
+      const int cj = col_base(j, N);
+      for (int i = j + lane; i < N; i += kWave) M[cj + i] = 0.0;
     }
     wave_sync();
   };
@@ -301,7 +475,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     flags |= kFlagPresolveRan;
     assemble(0.0);
     const long long t0 = wall_clock64();
-    const bool bad = ldlt_factor<SLOTS, MP>(M, N, lane);
+    const bool bad = ldlt_factor<SLOTS>(M, N, lane);
     ticks += wall_clock64() - t0;
     if (bad) {
       flags |= kFlagPresolveNumerical;
@@ -336,7 +510,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   if (!equality_constrained) {
     assemble(a.rho);                                   // :62-64
     const long long t0 = wall_clock64();
-    const bool bad = ldlt_factor<SLOTS, MP>(M, N, lane);   // :68 (info() unchecked in the reference)
+    const bool bad = ldlt_factor<SLOTS>(M, N, lane);   // :68 (info() unchecked in the reference)
     ticks += wall_clock64() - t0;
     if (bad) flags |= kFlagAdmmNumerical;
 
@@ -473,8 +647,11 @@ inline int slots_for(int N) { return (N + kWave - 1) / kWave; }
 template <int SLOTS>
 hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, int blocks, hipStream_t stream) {
   dim3 grid(blocks), block(kWave);
+  if constexpr (SLOTS > 4) {
+    if (mat_in_lds) return hipErrorInvalidValue;   // N > 256 never fits the 160 KiB LDS
+  }
   if (mat_in_lds) {
-    auto k = generic_kernel<SLOTS, true>;
+    auto k = generic_kernel<(SLOTS > 4 ? 4 : SLOTS), true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -490,13 +667,14 @@ hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, 
 
 size_t generic_lds_bytes(int n, int m, int nc) {
   const size_t N = (size_t)n + m;
-  return sizeof(double) * (N * (N + 1) / 2 + (size_t)nc + 2);
+  // + one panel of slack: the last panel's broadcast reads run up to 15 rows past the matrix
+  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel);
 }
 
 long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {
   if (generic_lds_bytes(n, m, nc) <= lds_limit) return 0;
   const long long N = (long long)n + m;
-  return N * (N + 1) / 2 + 8;
+  return (long long)packed_doubles((int)N) + 8;
 }
 
 static hipError_t launch_generic_blocks(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream) {

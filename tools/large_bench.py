@@ -1,11 +1,17 @@
+"""Generic-kernel timing for the large (n=114) and walking shapes, split by max_iter so the
+per-QP cost of presolve+factorizations (max_iter=0) and of one ADMM iteration can be read off."""
 import sys, numpy as np
 sys.path.insert(0, ".")
 from fcc_qp_amd import problems as P
 from tests import capi as C
 for shape, name, nb in [(P.LARGE, "large", 4096), (P.WALKING, "walking-generic", 4096)]:
     B = P.workload("W-sat", nb, shape, distinct=64)
-    s = C.Solver(*shape.ctor_args, batch=nb); s.set_options(**P.HARNESS_OPTIONS); s.set_kernel(C.KERNEL_GENERIC)
-    for rep in range(2):
-        s.solve_ok(*B.arrays()); ms = s.kernel_ms()
-    z, d = s.solution()
-    print(name, "kernel ms", ms, "->", nb / ms * 1e3, "solves/s; mean n_iter", np.mean([x.n_iter for x in d]), flush=True)
+    s = C.Solver(*shape.ctor_args, batch=nb); s.set_kernel(C.KERNEL_GENERIC)
+    for it in (0, 10, 100):
+        opt = dict(P.HARNESS_OPTIONS); opt["max_iter"] = it
+        s.set_options(**opt)
+        for rep in range(2):
+            s.solve_ok(*B.arrays()); ms = s.kernel_ms()
+        z, d = s.solution()
+        print(name, "max_iter", it, "kernel ms %.3f" % ms, "-> %.0f solves/s" % (nb / ms * 1e3),
+              "; mean n_iter", np.mean([x.n_iter for x in d]), flush=True)

@@ -52,6 +52,9 @@ def parse_args():
                     help="harness: fcc_qp_test.py:78-83 (headline); paper: fccqp.pdf Table 1 (max_iter=15, eps=1e-4)")
     ap.add_argument("--warm", action="store_true",
                     help="secondary mode: time warm-started solves (every step continues from the previous one)")
+    ap.add_argument("--inputs", default="f64", choices=["f64", "f32"],
+                    help="storage type of the resident inputs; f32 = BASELINE configs[2]'s fp32-storage "
+                         "path (widened on load, arithmetic stays fp64; the batch is the float-rounded problem)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     return ap.parse_args()
@@ -150,7 +153,11 @@ def main():
     solver.set_options(o)
     solver.set_warm_start(False)
     solver.set_kernel({"auto": F.KERNEL_AUTO, "generic": F.KERNEL_GENERIC, "fused": F.KERNEL_FUSED}[args.kernel])
+    if args.inputs == "f32":   # the problem IS the float-rounded one: oracle and CPU baseline see the same values
+        batch = P.Batch(*(a.astype(np.float32).astype(np.float64) for a in batch.arrays()))
     tens = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in batch.arrays()]   # resident in HBM
+    if args.inputs == "f32":
+        tens = [t.float() for t in tens]
     torch.cuda.synchronize()
 
     def step():
@@ -222,7 +229,7 @@ def main():
                             f"eps={options['eps_fcone']:g}/{options['eps_bound']:g} max_iter={options['max_iter']} "
                             f"({'fcc_qp_test.py:78-83' if args.options == 'harness' else 'fccqp.pdf Table 1'})",
                 "batch_per_gpu": nb, "global_batch": nb * world, "parallelism": f"batch-sharded x{world}, no collective",
-                "kernel": {1: "generic", 2: "fused"}[solver.kernel_in_use()],
+                "kernel": {1: "generic", 2: "fused"}[solver.kernel_in_use()], "input_storage": args.inputs,
                 "n_iter_mean": float(n_iter.mean()), "n_iter_at_max_frac": float(np.mean(n_iter == options["max_iter"])),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -176,6 +176,17 @@ void FCCQPBatch::SolveDevice(const double *dQ, const double *db, const double *d
   check(fccqp_solve_device(h_, dQ, db, dA_eq, db_eq, dfriction, dlb, dub, stream), h_,
         "FCCQPBatch::SolveDevice");
 }
+void FCCQPBatch::Solve(const float *Q, const float *b, const float *A_eq, const float *b_eq,
+                       const float *friction_coeffs, int n_friction, const float *lb,
+                       const float *ub) {
+  check(fccqp_solve_f32(h_, Q, b, A_eq, b_eq, friction_coeffs, n_friction, lb, ub), h_, "FCCQPBatch::Solve");
+}
+void FCCQPBatch::SolveDevice(const float *dQ, const float *db, const float *dA_eq,
+                             const float *db_eq, const float *dfriction, const float *dlb,
+                             const float *dub, void *stream) {
+  check(fccqp_solve_device_f32(h_, dQ, db, dA_eq, db_eq, dfriction, dlb, dub, stream), h_,
+        "FCCQPBatch::SolveDevice");
+}
 void FCCQPBatch::Synchronize() { check(fccqp_synchronize(h_), h_, "FCCQPBatch::Synchronize"); }
 
 FCCQPBatchSolution FCCQPBatch::GetSolution() const {

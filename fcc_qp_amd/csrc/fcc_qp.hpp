@@ -147,6 +147,12 @@ class FCCQPBatch {
   // device pointers, asynchronous on `stream` (hipStream_t; nullptr = HIP's default stream)
   void SolveDevice(const double *dQ, const double *db, const double *dA_eq, const double *db_eq,
                    const double *dfriction, const double *dlb, const double *dub, void *stream);
+  // fp32-storage inputs (float arrays of the same shapes; widened on load, arithmetic stays fp64:
+  // bit-identical to Solve on the widened values, half the input traffic; include/fccqp.h)
+  void Solve(const float *Q, const float *b, const float *A_eq, const float *b_eq,
+             const float *friction_coeffs, int n_friction, const float *lb, const float *ub);
+  void SolveDevice(const float *dQ, const float *db, const float *dA_eq, const float *db_eq,
+                   const float *dfriction, const float *dlb, const float *dub, void *stream);
   void Synchronize();
   FCCQPBatchSolution GetSolution() const;
   float LastKernelMilliseconds() const;

@@ -26,12 +26,14 @@ struct fccqp_solver {
   int kernel_used = FCCQP_KERNEL_GENERIC;
   bool solved = false;
   bool last_was_warm = false;
+  bool last_was_f32 = false;   // the last solve read Q / A_eq as float
   double last_solve_wall = 0.0;
   size_t lds_limit = 64 * 1024;
   hipStream_t stream = nullptr;      // the solver's own stream
   hipStream_t last_stream = nullptr; // stream of the last enqueue
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // staged inputs (host-pointer solve)
+  double *wb = nullptr, *wbeq = nullptr, *wmu = nullptr, *wlb = nullptr, *wub = nullptr;  // widened vectors
   double *dQ = nullptr, *db = nullptr, *dA = nullptr, *dbeq = nullptr, *dmu = nullptr,
          *dlb = nullptr, *dub = nullptr;
   // state / outputs
@@ -101,9 +103,21 @@ int ensure_staging(fccqp_solver *s) {
   return FCCQP_OK;
 }
 
+// f64 buffers for the small vectors of the fp32-storage entry points
+int ensure_vec_staging(fccqp_solver *s) {
+  if (s->wb) return FCCQP_OK;
+  const size_t B = (size_t)s->batch, n = (size_t)s->n, m = (size_t)s->m;
+  HIP_TRY(s, dmalloc(&s->wb, B * n));
+  HIP_TRY(s, dmalloc(&s->wbeq, B * m));
+  HIP_TRY(s, dmalloc(&s->wmu, B * n_mu(s)));
+  HIP_TRY(s, dmalloc(&s->wlb, B * n));
+  HIP_TRY(s, dmalloc(&s->wub, B * n));
+  return FCCQP_OK;
+}
+
 int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *dA,
             const double *dbeq, const double *dmu, const double *dlb, const double *dub,
-            hipStream_t stream) {
+            hipStream_t stream, bool qa_f32 = false) {
   fccqp::KernelArgs a{};
   a.n = s->n; a.m = s->m; a.nc = s->nc; a.s = s->s; a.batch = s->batch;
   a.warm_start = s->warm_start ? 1 : 0;
@@ -128,10 +142,10 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   hipError_t e;
   if (want_fused && can_fuse) {
     s->kernel_used = FCCQP_KERNEL_FUSED;
-    e = fccqp::launch_fused(a, stream);
+    e = fccqp::launch_fused(a, stream, qa_f32);
   } else {
     s->kernel_used = FCCQP_KERNEL_GENERIC;
-    e = fccqp::launch_generic(a, s->lds_limit, stream);
+    e = fccqp::launch_generic(a, s->lds_limit, stream, qa_f32);
   }
   if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "kernel launch", e);
   if (fb) {
@@ -141,13 +155,14 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     fccqp::KernelArgs b = a;
     b.fb_list = nullptr; b.fb_count = nullptr;
     b.inst_list = s->dfb_list; b.inst_count = cnt; b.next_count = cnt_next;
-    e = fccqp::launch_generic_list(b, s->lds_limit, blocks, stream);
+    e = fccqp::launch_generic_list(b, s->lds_limit, blocks, stream, qa_f32);
     if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "fallback kernel launch", e);
     s->solve_seq++;
   }
   HIP_TRY(s, hipEventRecord(s->ev1, stream));
   s->last_stream = stream;
   s->last_was_warm = s->warm_start;
+  s->last_was_f32 = qa_f32;
   s->solved = true;
   return FCCQP_OK;
 }
@@ -254,7 +269,7 @@ int fccqp_destroy(fccqp_solver *s) {
   if (!s) return FCCQP_OK;
   DeviceGuard g(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  void *ptrs[] = {s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, s->dx, s->dmux, s->dmulc,
+  void *ptrs[] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, s->dx, s->dmux, s->dmulc,
                   s->dmetrics, s->dwork, s->dniter, s->dflags, s->dticks, s->dphase, s->dfb_list,
                   s->dfb_count, s->dcod_ws};
   for (void *p : ptrs)
@@ -361,6 +376,63 @@ int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, cons
   hipStream_t st = (stream == FCCQP_STREAM_OWN) ? s->stream : reinterpret_cast<hipStream_t>(stream);
   s->last_solve_wall = 0.0;
   return enqueue(s, dQ, db, dA_eq, db_eq, dfriction, dlb, dub, st);
+}
+
+int fccqp_solve_device_f32(fccqp_solver *s, const float *dQ, const float *db, const float *dA_eq,
+                           const float *db_eq, const float *dfriction, const float *dlb,
+                           const float *dub, void *stream) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  const size_t B = (size_t)s->batch, n = (size_t)s->n, m = (size_t)s->m, nm = n_mu(s);
+  if ((n && (!dQ || !db || !dlb || !dub)) || (m && n && !dA_eq) || (m && !db_eq) || (nm && !dfriction))
+    return fail(s, FCCQP_ERR_INVALID_ARG, "null device pointer");
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(s, FCCQP_ERR_NO_DEVICE, "hipSetDevice failed");
+  int rc = ensure_vec_staging(s);
+  if (rc != FCCQP_OK) return rc;
+  hipStream_t st = (stream == FCCQP_STREAM_OWN) ? s->stream : reinterpret_cast<hipStream_t>(stream);
+  HIP_TRY(s, fccqp::launch_widen(db, s->wb, B * n, st));
+  HIP_TRY(s, fccqp::launch_widen(db_eq, s->wbeq, B * m, st));
+  HIP_TRY(s, fccqp::launch_widen(dfriction, s->wmu, B * nm, st));
+  HIP_TRY(s, fccqp::launch_widen(dlb, s->wlb, B * n, st));
+  HIP_TRY(s, fccqp::launch_widen(dub, s->wub, B * n, st));
+  s->last_solve_wall = 0.0;
+  return enqueue(s, reinterpret_cast<const double *>(dQ), s->wb, reinterpret_cast<const double *>(dA_eq),
+                 s->wbeq, s->wmu, s->wlb, s->wub, st, /*qa_f32=*/true);
+}
+
+int fccqp_solve_f32(fccqp_solver *s, const float *Q, const float *b, const float *A_eq,
+                    const float *b_eq, const float *friction_coeffs, int n_friction,
+                    const float *lb, const float *ub) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  const size_t B = (size_t)s->batch, n = (size_t)s->n, m = (size_t)s->m, nm = n_mu(s);
+  if ((n && (!Q || !b || !lb || !ub)) || (m && n && !A_eq) || (m && !b_eq) || (nm && !friction_coeffs))
+    return fail(s, FCCQP_ERR_INVALID_ARG, "null input pointer");
+  if (n_friction < (int)nm) return fail(s, FCCQP_ERR_FRICTION_COEFFS, "friction_coeffs too short");
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(s, FCCQP_ERR_NO_DEVICE, "hipSetDevice failed");
+  int rc = ensure_staging(s);
+  if (rc != FCCQP_OK) return rc;
+  hipStream_t st = s->stream;
+  // Q and A_eq travel and stay as float (in the front half of the f64 staging buffers); the small
+  // vectors are widened here on the host
+  HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));
+  if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(float) * B * m * n, hipMemcpyHostToDevice, st));
+  std::vector<double> wb(b, b + B * n), wbeq(b_eq, b_eq + (m ? B * m : 0)), wlb(lb, lb + B * n),
+      wub(ub, ub + B * n), wmu(B * nm);
+  for (size_t i = 0; i < B; ++i)
+    for (size_t c = 0; c < nm; ++c) wmu[i * nm + c] = (double)friction_coeffs[i * (size_t)n_friction + c];
+  HIP_TRY(s, hipMemcpyAsync(s->db, wb.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+  if (m) HIP_TRY(s, hipMemcpyAsync(s->dbeq, wbeq.data(), sizeof(double) * B * m, hipMemcpyHostToDevice, st));
+  if (nm) HIP_TRY(s, hipMemcpyAsync(s->dmu, wmu.data(), sizeof(double) * B * nm, hipMemcpyHostToDevice, st));
+  HIP_TRY(s, hipMemcpyAsync(s->dlb, wlb.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(s, hipMemcpyAsync(s->dub, wub.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+  rc = enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st, /*qa_f32=*/true);
+  if (rc != FCCQP_OK) return rc;
+  HIP_TRY(s, hipStreamSynchronize(st));   // also keeps the host vectors alive until the copies ran
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  s->last_solve_wall = std::chrono::duration<double>(t1 - t0).count();
+  return FCCQP_OK;
 }
 
 int fccqp_synchronize(fccqp_solver *s) {
@@ -479,9 +551,10 @@ int fccqp_phase_seconds(fccqp_solver *s, double out[8]) {
 int fccqp_algorithmic_bytes(const fccqp_solver *s, long long *bytes) {
   if (!s || !bytes) return FCCQP_ERR_INVALID_ARG;
   const long long n = s->n, m = s->m, nc = s->nc, B = s->batch;
-  long long elems = n * n + m * n + 4 * n + m + nc / 3;
-  if (s->warm_start) elems += 2 * (2 * n + nc);               // state read + written
-  *bytes = 8 * B * elems;
+  const long long in_elems = n * n + m * n + 3 * n + m + nc / 3;   // the inputs ...
+  long long io_elems = n;                                          // ... and z
+  if (s->warm_start) io_elems += 2 * (2 * n + nc);                 // state read + written
+  *bytes = B * ((s->last_was_f32 ? 4 : 8) * in_elems + 8 * io_elems);
   return FCCQP_OK;
 }
 

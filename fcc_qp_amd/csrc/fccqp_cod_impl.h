@@ -78,6 +78,7 @@ __device__ void apply_reflector(const double *vess, double tau, double *y, int l
 
 // Minimum-norm least-squares x0 of instance `inst` into a.x; W = this block's workspace
 // (cod_workspace_doubles(n, m) doubles).
+template <class TIN>
 __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
   const int lane = threadIdx.x;
   const int n = a.n, m = a.m, N = n + m;
@@ -91,8 +92,8 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
   int *perm = reinterpret_cast<int *>(y + N);
   {
 
-    const double *Q = a.Q + (size_t)inst * n * n;
-    const double *Ae = a.A + (size_t)inst * m * n;
+    const TIN *Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
+    const TIN *Ae = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * m * n;
     const double *bq = a.b + (size_t)inst * n;
     const double *beq = a.b_eq + (size_t)inst * m;
     // full symmetric KKT [[Q_sym, A^T],[A, 0]] with Q taken from its lower triangle, like the
@@ -100,9 +101,9 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
     for (int e = lane; e < N * N; e += kWave) {
       const int i = e % N, j = e / N;
       double v;
-      if (i < n && j < n) v = Q[(size_t)i * n + j];   // the reference hands COD the matrix as assembled
-      else if (i >= n && j < n) v = Ae[(size_t)(i - n) * n + j];
-      else if (i < n && j >= n) v = Ae[(size_t)(j - n) * n + i];
+      if (i < n && j < n) v = (double)Q[(size_t)i * n + j];   // the reference hands COD the matrix as assembled
+      else if (i >= n && j < n) v = (double)Ae[(size_t)(i - n) * n + j];
+      else if (i < n && j >= n) v = (double)Ae[(size_t)(j - n) * n + i];
       else v = 0.0;
       A[e] = v;
     }

@@ -16,6 +16,10 @@ struct KernelArgs {
   int warm_start;                               // (:133)
   int max_iter;                                 // FCCQPOptions (:30-35)
   double rho, eps_fcone, eps_bound;
+  // Q and A_eq address float arrays instead when a launcher is called with qa_f32 = true (the
+  // fp32-storage entry points): values are widened on load, all arithmetic is fp64.  The flag is a
+  // template parameter of the kernels, not a field here: the fused kernel's register allocation is
+  // sensitive to the kernarg layout (+3% run time from one extra int).
   const double *Q, *b, *A, *b_eq, *mu, *lb, *ub;
   // warm-start state, also the outputs: x doubles as z (reference GetSolution: z = x_, cpp:205)
   double *x, *mu_x, *mu_lc;
@@ -54,9 +58,13 @@ constexpr int kGenericMaxN = 512;
 size_t generic_lds_bytes(int n, int m, int nc);
 // Doubles of global workspace per block when the packed KKT does not fit in LDS (else 0).
 long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit);
-hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream);
+hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream, bool qa_f32);
 // list mode: a.inst_list / a.inst_count set; `blocks` persistent one-wave workgroups
-hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream);
+hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream,
+                               bool qa_f32);
+
+// widens count floats to doubles (small per-instance vectors of the fp32-storage entry points)
+hipError_t launch_widen(const float *src, double *dst, size_t count, hipStream_t stream);
 
 // ---- presolve fallback workspace (fccqp_cod_impl.h) ---------------------------------------------
 long long cod_workspace_doubles_host(int n, int m);
@@ -64,6 +72,6 @@ long long cod_workspace_doubles_host(int n, int m);
 // ---- fused shape-specialised kernels (fccqp_fused.hip) ---------------------------------------
 bool fused_supported(int n, int m, int nc, int s);
 bool fused_pointers_ok(const KernelArgs &a);  // 16-byte alignment of Q and A_eq
-hipError_t launch_fused(const KernelArgs &a, hipStream_t stream);
+hipError_t launch_fused(const KernelArgs &a, hipStream_t stream, bool qa_f32);
 
 }  // namespace fccqp

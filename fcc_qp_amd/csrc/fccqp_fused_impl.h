@@ -430,7 +430,11 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
   }
 }
 
-template <class SH>
+// TIN: storage type of Q and A_eq (double, or float for the fp32-storage entry points: widened on
+// load).  A template parameter rather than a run-time flag: an extra code path in the assembly
+// phase perturbed the register allocation of the whole kernel (36 VGPR spills, +30% on the ADMM
+// loop), and even an unused extra kernarg field cost 3%.
+template <class SH, class TIN>
 __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   constexpr int n = SH::n, m = SH::m, nc = SH::nc, s0 = SH::s, N = SH::N;
   __shared__ __attribute__((aligned(16))) double lds_raw[SH::kLdsDoubles];
@@ -442,8 +446,8 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   const int inst = blockIdx.x;
   if (inst >= a.batch) return;
 
-  const double *__restrict__ Q = a.Q + (size_t)inst * n * n;
-  const double *__restrict__ A = a.A + (size_t)inst * m * n;
+  const TIN *__restrict__ Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
+  const TIN *__restrict__ A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * m * n;
   const double *__restrict__ bq = a.b + (size_t)inst * n;
   const double *__restrict__ beq = a.b_eq + (size_t)inst * m;
   const double *__restrict__ mup = a.mu + (size_t)inst * (nc / 3);
@@ -481,6 +485,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   // bottom, which pairs a short row of the triangle with a long one (about half the lanes carry
   // data each trip) and reads only the lower triangle of Q from HBM.
   auto assemble = [&](double rho) {
+    using T2 = TIN __attribute__((ext_vector_type(2)));
     if constexpr (n % 2 == 0) {
       const int half = lane >> 5, l = lane & 31, j0 = 2 * l;
       const int jc = (j0 < n) ? j0 : 0;
@@ -488,15 +493,15 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       // all global loads first, unconditionally (idle lanes re-read a pair another lane needs), so that they
       // are in flight together: a load inside the per-row branch is waited for before the next
       // row's load is even issued (30 serialised HBM round trips per assembly)
-      const d2 *Q2 = reinterpret_cast<const d2 *>(Q);
-      const d2 *A2 = reinterpret_cast<const d2 *>(A);
       constexpr int mh = (m + 1) / 2;
-      d2 vq[n / 2], va[mh];
+      // lanes above the diagonal re-read the row's first pair (same cache line): only the lower
+      // triangle of Q comes from HBM.  n even: element (row, j) is pair-aligned for even j
+      const T2 *Q2 = reinterpret_cast<const T2 *>(Q);
+      const T2 *A2 = reinterpret_cast<const T2 *>(A);
+      T2 vq[n / 2], va[mh];   // widened (float storage) only at the store: no second register image
 #pragma unroll
       for (int it = 0; it < n / 2; ++it) {
         const int row = half ? (n - 1 - it) : it;
-        // lanes above the diagonal re-read the row's first pair (same cache line): only the lower
-        // triangle of Q comes from HBM.  n even: (row, j) is 16-byte aligned for even j
         vq[it] = Q2[(row * n + ((j0 < n && j0 <= row) ? j0 : 0)) >> 1];
       }
 #pragma unroll
@@ -508,24 +513,24 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       for (int it = 0; it < n / 2; ++it) {
         const int row = half ? (n - 1 - it) : it;
         if (j0 < n && j0 <= row) {
-          M[cb0 + row] = vq[it].x + ((row == j0) ? rho : 0.0);
-          if (j0 + 1 <= row) M[cb1 + row] = vq[it].y + ((row == j0 + 1) ? rho : 0.0);
+          M[cb0 + row] = (double)vq[it].x + ((row == j0) ? rho : 0.0);
+          if (j0 + 1 <= row) M[cb1 + row] = (double)vq[it].y + ((row == j0 + 1) ? rho : 0.0);
         }
       }
 #pragma unroll
       for (int it = 0; it < mh; ++it) {
         const int r = half ? (it + mh) : it;
         if (j0 < n && r < m) {
-          M[cb0 + n + r] = va[it].x;
-          M[cb1 + n + r] = va[it].y;
+          M[cb0 + n + r] = (double)va[it].x;
+          M[cb1 + n + r] = (double)va[it].y;
         }
       }
     } else {
       for (int e = lane; e < n * n; e += kWave) {
         const int i = e / n, j = e - i * n;
-        if (i >= j) M[SH::cbase(j) + i] = Q[e] + ((i == j) ? rho : 0.0);
+        if (i >= j) M[SH::cbase(j) + i] = (double)Q[e] + ((i == j) ? rho : 0.0);
       }
-      for (int e = lane; e < m * n; e += kWave) { const int r = e / n; M[SH::cbase(e - r * n) + n + r] = A[e]; }
+      for (int e = lane; e < m * n; e += kWave) { const int r = e / n; M[SH::cbase(e - r * n) + n + r] = (double)A[e]; }
     }
     // zero block: rows >= n of columns >= n (column j holds rows j..N-1: at most m <= 64 of them)
     {
@@ -538,7 +543,6 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     }
     lds_fence();
   };
-
   // [-b; b_eq] (fcc_qp.cpp:149-150) into vbuf[0..N)
   auto stage_rhs = [&]() {
     const double *bp = fresh(bq), *ep = fresh(beq);

@@ -379,7 +379,7 @@ __device__ __forceinline__ void project_cone3(double fx, double fy, double fz, d
 
 // Solves instance `inst`.  x0_given: the presolve was done elsewhere (fallback pass): x0 comes from
 // a.x, the duals start at zero, the presolve flags are reported as "ran, numerical, COD".
-template <int SLOTS, bool MAT_IN_LDS>
+template <int SLOTS, bool MAT_IN_LDS, class TIN>
 __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst, const bool x0_given) {
   const int lane = threadIdx.x;
   const int n = a.n, m = a.m, nc = a.nc, s0 = a.s, N = n + m;
@@ -392,8 +392,9 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   else M = a.workspace + (long long)blockIdx.x * a.workspace_stride;
   lds_f64 *cone_buf = (lds_f64 *)(MAT_IN_LDS ? (lds + npack) : lds);  // nc doubles of cross-lane scratch
 
-  const double *Q = a.Q + (size_t)inst * n * n;
-  const double *A = a.A + (size_t)inst * m * n;
+  // TIN: storage type of Q / A_eq (double, or float for the fp32-storage entry points)
+  const TIN *Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
+  const TIN *A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * m * n;
   const double *bq = a.b + (size_t)inst * n;
   const double *beq = a.b_eq + (size_t)inst * m;
   const double *mu = a.mu + (size_t)inst * (nc / 3);
@@ -449,8 +450,8 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const int i = (i0 + r < N) ? i0 + r : N - 1;
-            const double *src = (i < n) ? Q + (size_t)i * n : A + (size_t)(i - n) * n;
-            v[r] = src[jc];
+            const TIN *src = (i < n) ? Q + (size_t)i * n : A + (size_t)(i - n) * n;
+            v[r] = (double)src[jc];
           }
           const int cj = col_base(jc, N);
 #pragma unroll
@@ -626,7 +627,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   }
 }
 
-template <int SLOTS, bool MAT_IN_LDS>
+template <int SLOTS, bool MAT_IN_LDS, class TIN>
 __global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   if (a.inst_list) {  // list mode (fallback launch): persistent blocks walk the fallback list
@@ -634,36 +635,49 @@ __global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_count = 0;
     for (int li = blockIdx.x; li < total; li += gridDim.x) {
       const int inst = a.inst_list[li];
-      cod::cod_presolve(a, inst, a.cod_ws + (long long)blockIdx.x * a.cod_stride);   // fcc_qp.cpp:165,176
-      solve_instance<SLOTS, MAT_IN_LDS>(a, lds, inst, true);
+      cod::cod_presolve<TIN>(a, inst, a.cod_ws + (long long)blockIdx.x * a.cod_stride);   // fcc_qp.cpp:165,176
+      solve_instance<SLOTS, MAT_IN_LDS, TIN>(a, lds, inst, true);
     }
   } else if ((int)blockIdx.x < a.batch) {
-    solve_instance<SLOTS, MAT_IN_LDS>(a, lds, (int)blockIdx.x, false);
+    solve_instance<SLOTS, MAT_IN_LDS, TIN>(a, lds, (int)blockIdx.x, false);
   }
 }
 
 inline int slots_for(int N) { return (N + kWave - 1) / kWave; }
 
-template <int SLOTS>
+template <int SLOTS, class TIN>
 hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, int blocks, hipStream_t stream) {
   dim3 grid(blocks), block(kWave);
   if constexpr (SLOTS > 4) {
     if (mat_in_lds) return hipErrorInvalidValue;   // N > 256 never fits the 160 KiB LDS
   }
   if (mat_in_lds) {
-    auto k = generic_kernel<(SLOTS > 4 ? 4 : SLOTS), true>;
+    auto k = generic_kernel<(SLOTS > 4 ? 4 : SLOTS), true, TIN>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, block, lds_bytes, stream, a);
   } else {
-    auto k = generic_kernel<SLOTS, false>;
+    auto k = generic_kernel<SLOTS, false, TIN>;
     hipLaunchKernelGGL(k, grid, block, lds_bytes, stream, a);
   }
   return hipGetLastError();
 }
 
+__global__ void widen_kernel(const float *__restrict__ src, double *__restrict__ dst, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (double)src[i];
+}
+
 }  // namespace
+
+hipError_t launch_widen(const float *src, double *dst, size_t count, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  const size_t want = (count + 255) / 256;
+  const int blocks = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(widen_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, count);
+  return hipGetLastError();
+}
 
 size_t generic_lds_bytes(int n, int m, int nc) {
   const size_t N = (size_t)n + m;
@@ -677,6 +691,7 @@ long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {
   return (long long)packed_doubles((int)N) + 8;
 }
 
+template <class TIN>
 static hipError_t launch_generic_blocks(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream) {
   const int N = a.n + a.m;
   if (N > kGenericMaxN) return hipErrorInvalidValue;
@@ -685,20 +700,23 @@ static hipError_t launch_generic_blocks(const KernelArgs &a, size_t lds_limit, i
   const size_t lds = in_lds ? generic_lds_bytes(a.n, a.m, a.nc) : sizeof(double) * ((size_t)a.nc + 2);
   const int slots = slots_for(N > 0 ? N : 1);
   switch (slots) {
-    case 1: return launch_slots<1>(a, in_lds, lds, blocks, stream);
-    case 2: return launch_slots<2>(a, in_lds, lds, blocks, stream);
-    case 3: return launch_slots<3>(a, in_lds, lds, blocks, stream);
-    case 4: return launch_slots<4>(a, in_lds, lds, blocks, stream);
-    default: return launch_slots<8>(a, in_lds, lds, blocks, stream);
+    case 1: return launch_slots<1, TIN>(a, in_lds, lds, blocks, stream);
+    case 2: return launch_slots<2, TIN>(a, in_lds, lds, blocks, stream);
+    case 3: return launch_slots<3, TIN>(a, in_lds, lds, blocks, stream);
+    case 4: return launch_slots<4, TIN>(a, in_lds, lds, blocks, stream);
+    default: return launch_slots<8, TIN>(a, in_lds, lds, blocks, stream);
   }
 }
 
-hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream) {
-  return launch_generic_blocks(a, lds_limit, a.batch, stream);
+hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t stream, bool qa_f32) {
+  return qa_f32 ? launch_generic_blocks<float>(a, lds_limit, a.batch, stream)
+                : launch_generic_blocks<double>(a, lds_limit, a.batch, stream);
 }
 
-hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream) {
-  return launch_generic_blocks(a, lds_limit, blocks, stream);
+hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream,
+                               bool qa_f32) {
+  return qa_f32 ? launch_generic_blocks<float>(a, lds_limit, blocks, stream)
+                : launch_generic_blocks<double>(a, lds_limit, blocks, stream);
 }
 
 long long cod_workspace_doubles_host(int n, int m) { return cod_workspace_doubles(n, m); }

@@ -56,7 +56,9 @@ py::array_t<double> to_numpy(const std::vector<double> &v) {
   return out;
 }
 
-void expect_shape(const carray &a, std::initializer_list<py::ssize_t> shape, const char *name) {
+template <class T>
+void expect_shape_t(const py::array_t<T, py::array::c_style | py::array::forcecast> &a,
+                    std::initializer_list<py::ssize_t> shape, const char *name) {
   bool ok = a.ndim() == (py::ssize_t)shape.size();
   if (ok) {
     int k = 0;
@@ -68,6 +70,42 @@ void expect_shape(const carray &a, std::initializer_list<py::ssize_t> shape, con
     s += ")";
     throw py::value_error(s);
   }
+}
+
+// FCCQPBatch.Solve for element type T (double, or float for the fp32-storage path)
+template <class T>
+void batch_solve(FCCQPBatch &self, const py::object &Qo, const py::object &bo, const py::object &Ao,
+                 const py::object &beo, const py::object &fo, const py::object &lo, const py::object &uo) {
+  using arr = py::array_t<T, py::array::c_style | py::array::forcecast>;
+  const arr Q = arr::ensure(Qo), b = arr::ensure(bo), A_eq = arr::ensure(Ao), b_eq = arr::ensure(beo),
+            friction_coeffs = arr::ensure(fo), lb = arr::ensure(lo), ub = arr::ensure(uo);
+  if (!Q || !b || !A_eq || !b_eq || !friction_coeffs || !lb || !ub)
+    throw py::type_error("FCCQPBatch.Solve: arguments must be convertible to numeric arrays");
+  const py::ssize_t B = self.batch(), n = self.num_vars(), mm = self.num_equality_constraints();
+  const py::ssize_t nf = self.nc() / 3;
+  expect_shape_t<T>(Q, {B, n, n}, "Q");
+  expect_shape_t<T>(b, {B, n}, "b");
+  if (mm > 0) expect_shape_t<T>(A_eq, {B, mm, n}, "A_eq");
+  if (mm > 0) expect_shape_t<T>(b_eq, {B, mm}, "b_eq");
+  expect_shape_t<T>(lb, {B, n}, "lb");
+  expect_shape_t<T>(ub, {B, n}, "ub");
+  // friction_coeffs: [B, k] or a single [k] row shared by every instance, k >= nc/3
+  std::vector<T> tiled;
+  const T *fp = friction_coeffs.data();
+  int k = 0;
+  if (friction_coeffs.ndim() == 2 && friction_coeffs.shape(0) == B) {
+    k = (int)friction_coeffs.shape(1);
+  } else if (friction_coeffs.ndim() == 1) {
+    k = (int)friction_coeffs.shape(0);
+    tiled.resize((size_t)B * (size_t)k);
+    for (py::ssize_t i = 0; i < B; ++i) std::copy(fp, fp + k, tiled.begin() + (size_t)i * (size_t)k);
+    fp = tiled.data();
+  } else {
+    throw py::value_error("friction_coeffs must have shape (batch, k) or (k,)");
+  }
+  if (k < nf) throw py::index_error("friction_coeffs has fewer than nc/3 entries per instance");
+  py::gil_scoped_release release;
+  self.Solve(Q.data(), b.data(), A_eq.data(), b_eq.data(), fp, k, lb.data(), ub.data());
 }
 
 template <class T>
@@ -185,51 +223,41 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def_property_readonly("batch", &FCCQPBatch::batch)
       .def(
           "Solve",
-          [](FCCQPBatch &self, const carray &Q, const carray &b, const carray &A_eq, const carray &b_eq,
-             const carray &friction_coeffs, const carray &lb, const carray &ub) {
-            const py::ssize_t B = self.batch(), n = self.num_vars(), mm = self.num_equality_constraints();
-            const py::ssize_t nf = self.nc() / 3;
-            expect_shape(Q, {B, n, n}, "Q");
-            expect_shape(b, {B, n}, "b");
-            if (mm > 0) expect_shape(A_eq, {B, mm, n}, "A_eq");
-            if (mm > 0) expect_shape(b_eq, {B, mm}, "b_eq");
-            expect_shape(lb, {B, n}, "lb");
-            expect_shape(ub, {B, n}, "ub");
-            // friction_coeffs: [B, k] or a single [k] row shared by every instance, k >= nc/3
-            std::vector<double> tiled;
-            const double *fp = friction_coeffs.data();
-            int k = 0;
-            if (friction_coeffs.ndim() == 2 && friction_coeffs.shape(0) == B) {
-              k = (int)friction_coeffs.shape(1);
-            } else if (friction_coeffs.ndim() == 1) {
-              k = (int)friction_coeffs.shape(0);
-              tiled.resize((size_t)B * (size_t)k);
-              for (py::ssize_t i = 0; i < B; ++i)
-                std::copy(fp, fp + k, tiled.begin() + (size_t)i * (size_t)k);
-              fp = tiled.data();
-            } else {
-              throw py::value_error("friction_coeffs must have shape (batch, k) or (k,)");
-            }
-            if (k < nf) throw py::index_error("friction_coeffs has fewer than nc/3 entries per instance");
-            py::gil_scoped_release release;
-            self.Solve(Q.data(), b.data(), A_eq.data(), b_eq.data(), fp, k, lb.data(), ub.data());
+          [](FCCQPBatch &self, const py::object &Q, const py::object &b, const py::object &A_eq,
+             const py::object &b_eq, const py::object &friction_coeffs, const py::object &lb,
+             const py::object &ub) {
+            // a float32 Q selects the fp32-storage path (every argument is then taken as float32;
+            // the kernels widen on load and compute in fp64); anything else is converted to float64
+            const py::array qa = py::array::ensure(Q);
+            if (qa && qa.dtype().is(py::dtype::of<float>()))
+              batch_solve<float>(self, Q, b, A_eq, b_eq, friction_coeffs, lb, ub);
+            else
+              batch_solve<double>(self, Q, b, A_eq, b_eq, friction_coeffs, lb, ub);
           },
           py::arg("Q"), py::arg("b"), py::arg("A_eq"), py::arg("b_eq"), py::arg("friction_coeffs"),
           py::arg("lb"), py::arg("ub"))
       .def(
           "SolveDevice",
           [](FCCQPBatch &self, std::uintptr_t Q, std::uintptr_t b, std::uintptr_t A_eq, std::uintptr_t b_eq,
-             std::uintptr_t friction_coeffs, std::uintptr_t lb, std::uintptr_t ub, std::uintptr_t stream) {
-            self.SolveDevice(reinterpret_cast<const double *>(Q), reinterpret_cast<const double *>(b),
-                             reinterpret_cast<const double *>(A_eq), reinterpret_cast<const double *>(b_eq),
-                             reinterpret_cast<const double *>(friction_coeffs),
-                             reinterpret_cast<const double *>(lb), reinterpret_cast<const double *>(ub),
-                             reinterpret_cast<void *>(stream));
+             std::uintptr_t friction_coeffs, std::uintptr_t lb, std::uintptr_t ub, std::uintptr_t stream,
+             bool float32) {
+            if (float32)
+              self.SolveDevice(reinterpret_cast<const float *>(Q), reinterpret_cast<const float *>(b),
+                               reinterpret_cast<const float *>(A_eq), reinterpret_cast<const float *>(b_eq),
+                               reinterpret_cast<const float *>(friction_coeffs),
+                               reinterpret_cast<const float *>(lb), reinterpret_cast<const float *>(ub),
+                               reinterpret_cast<void *>(stream));
+            else
+              self.SolveDevice(reinterpret_cast<const double *>(Q), reinterpret_cast<const double *>(b),
+                               reinterpret_cast<const double *>(A_eq), reinterpret_cast<const double *>(b_eq),
+                               reinterpret_cast<const double *>(friction_coeffs),
+                               reinterpret_cast<const double *>(lb), reinterpret_cast<const double *>(ub),
+                               reinterpret_cast<void *>(stream));
           },
           py::arg("Q"), py::arg("b"), py::arg("A_eq"), py::arg("b_eq"), py::arg("friction_coeffs"),
-          py::arg("lb"), py::arg("ub"), py::arg("stream") = 0,
+          py::arg("lb"), py::arg("ub"), py::arg("stream") = 0, py::arg("float32") = false,
           "Asynchronous solve from device pointers (ints, e.g. torch.Tensor.data_ptr()) of "
-          "instance-major float64 arrays resident on the solver's GPU.")
+          "instance-major float64 (or, with float32=True, float32) arrays resident on the solver's GPU.")
       .def("Synchronize", &FCCQPBatch::Synchronize, py::call_guard<py::gil_scoped_release>())
       .def("GetSolution", &FCCQPBatch::GetSolution)
       .def("LastKernelMilliseconds", &FCCQPBatch::LastKernelMilliseconds)

@@ -145,6 +145,20 @@ int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double 
 int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, const double *dA_eq,
                        const double *db_eq, const double *dfriction, const double *dlb,
                        const double *dub, void *stream);
+
+/* fp32-STORAGE forms (BASELINE.json configs[2]).  Same shapes and layout, float arrays.  Every
+ * value is widened to double as it is loaded and all arithmetic stays fp64, so the result is bit
+ * for bit that of fccqp_solve on the widened values, while the HBM / PCIe traffic of the call is
+ * halved (Q and A_eq, 98% of the bytes, are read as float by the kernels; the small vectors are
+ * widened into solver-owned buffers first).  The reference has no float path (Eigen::MatrixXd
+ * throughout, src/fcc_qp.hpp:114-117); these replace the same code as fccqp_solve
+ * (src/fcc_qp.cpp:114-191) for callers that log or generate QPs in float. */
+int fccqp_solve_f32(fccqp_solver *s, const float *Q, const float *b, const float *A_eq,
+                    const float *b_eq, const float *friction_coeffs, int n_friction,
+                    const float *lb, const float *ub);
+int fccqp_solve_device_f32(fccqp_solver *s, const float *dQ, const float *db, const float *dA_eq,
+                           const float *db_eq, const float *dfriction, const float *dlb,
+                           const float *dub, void *stream);
 int fccqp_synchronize(fccqp_solver *s);
 
 /* ---- results      (replaces FCCQP::GetSolution, reference src/fcc_qp.cpp:194-207) ----------- */
@@ -174,7 +188,8 @@ int fccqp_last_kernel_ms(fccqp_solver *s, float *ms);
  * first call enables the stamps for subsequent solves and returns zeros. */
 int fccqp_phase_seconds(fccqp_solver *s, double out[8]);
 /* Compulsory HBM bytes one solve of the whole batch moves:
- * 8 * batch * (n^2 + m*n + 4n + m + nc/3), plus the warm-start state when warm. */
+ * 8 * batch * (n^2 + m*n + 4n + m + nc/3), plus the warm-start state when warm.  After an
+ * fp32-storage solve the seven inputs count 4 bytes per element (z and the state stay 8). */
 int fccqp_algorithmic_bytes(const fccqp_solver *s, long long *bytes);
 
 #ifdef __cplusplus

@@ -36,6 +36,7 @@ def declared_functions():
 
 
 _dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
 _lib = None
 
 
@@ -61,6 +62,8 @@ def lib():
         L.fccqp_get_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.fccqp_solve.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.fccqp_solve_device.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]
+        L.fccqp_solve_f32.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp]
+        L.fccqp_solve_device_f32.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]
         L.fccqp_synchronize.argtypes = [C.c_void_p]
         L.fccqp_get_solution.argtypes = [C.c_void_p, _dp, C.POINTER(Details)]
         L.fccqp_get_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
@@ -127,6 +130,16 @@ class Solver:
 
     def solve_ok(self, *a):
         self._ck(self.solve(*a), "solve")
+
+    def solve_f32(self, Q, b, A, b_eq, mu, lb, ub):
+        """fp32-storage entry point: every array is handed over as float32."""
+        arrs = [np.ascontiguousarray(np.asarray(a, dtype=np.float32)) for a in (Q, b, A, b_eq, mu, lb, ub)]
+        nf = arrs[4].shape[-1] if arrs[4].ndim >= 1 and arrs[4].size else 0
+        return self.L.fccqp_solve_f32(self.h, *(a.ctypes.data_as(_fp) for a in arrs[:5]), int(nf),
+                                      arrs[5].ctypes.data_as(_fp), arrs[6].ctypes.data_as(_fp))
+
+    def solve_f32_ok(self, *a):
+        self._ck(self.solve_f32(*a), "solve_f32")
 
     def solution(self):
         z = np.zeros((self.batch, self.n))

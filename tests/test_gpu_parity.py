@@ -289,3 +289,53 @@ def test_cone_projection_branches_and_fz_zero_quirk(oracle, kernel):
     # the quirk itself: lambda_c_bar == 0 for (1, 0, 0)  =>  mu_lambda_c == x
     iq = list(cases).index("fz_zero_quirk")
     assert np.allclose(mulc[iq][:3], z[iq][3:6], rtol=0, atol=1e-15) and abs(z[iq][3] - 1.0) < 1e-12
+
+
+def _as_f32_batch(B):
+    """The batch with every array rounded to float32 (what an fp32 log holds), as float32 arrays
+    and as the same values widened back to float64."""
+    f32 = [np.ascontiguousarray(a.astype(np.float32)) for a in B.arrays()]
+    return f32, P.Batch(*(a.astype(np.float64) for a in f32))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dims", [P.WALKING.ctor_args, P.LARGE.ctor_args, (12, 5, 6, 3), (33, 9, 9, 24)],
+                         ids=["walking", "large", "mini", "odd"])
+def test_fp32_storage_inputs_equal_fp64_path_on_widened_values(oracle, dims, kernel):
+    """fccqp_solve_f32 (BASELINE configs[2]): float arrays, widened on load, fp64 arithmetic --
+    bit for bit the result of fccqp_solve on the widened values, and within tolerance of the oracle."""
+    nb = 24
+    dims = tuple(dims)
+    if dims == tuple(P.WALKING.ctor_args):
+        B, opts = P.workload("W-mix", nb, P.WALKING), P.HARNESS_OPTIONS
+    elif dims == tuple(P.LARGE.ctor_args):
+        B, opts = P.workload("W-mix", nb, P.LARGE), P.HARNESS_OPTIONS
+    else:
+        rng = np.random.default_rng(sum(dims) + 7)
+        B = P.stack([_random_qp(rng, *dims) for _ in range(nb)])
+        opts = dict(max_iter=60, rho=0.1, eps_fcone=1e-7, eps_bound=1e-7)
+    n, m, nc, _ = dims
+    f32, wide = _as_f32_batch(B)
+    s = CAPI.Solver(*dims, batch=nb); s.set_options(**opts); s.set_kernel(kernel)
+    s.solve_f32_ok(*f32); z32, d32 = s.solution()
+    bytes32 = s.algorithmic_bytes()
+    s.solve_ok(*wide.arrays()); z64, d64 = s.solution()
+    assert np.array_equal(z32, z64)
+    assert [x.n_iter for x in d32] == [x.n_iter for x in d64]
+    assert s.algorithmic_bytes() == 8 * nb * (n * n + m * n + 4 * n + m + nc // 3)
+    assert bytes32 == nb * (4 * (n * n + m * n + 3 * n + m + nc // 3) + 8 * n)
+    z_ref, it_ref, _, _ = oracle.solve_batch(dims, opts, *wide.arrays(), nthreads=2)
+    assert_parity(z32, [x.n_iter for x in d32], z_ref, it_ref, tol=Z_TOL, what="fp32 storage")
+
+
+def test_fp32_storage_rank_deficient_presolve(oracle):
+    """The COD fallback reads Q / A_eq through the same float path."""
+    base = P.workload("W-mix", 6, P.WALKING)
+    qps = [base.instance(i) for i in range(6)]
+    qps[4] = _dead_variable(qps[4], 25)
+    f32, wide = _as_f32_batch(P.stack(qps))
+    s = CAPI.Solver(*P.WALKING.ctor_args, batch=6); s.set_options(**P.HARNESS_OPTIONS)
+    s.solve_f32_ok(*f32); z32, d32 = s.solution()
+    assert d32[4].flags & CAPI.FLAG_PRESOLVE_COD
+    z_ref, it_ref, _ = oracle_batch(oracle, P.WALKING.ctor_args, P.HARNESS_OPTIONS, wide)
+    assert_parity(z32, [x.n_iter for x in d32], z_ref, it_ref, tol=Z_TOL, what="fp32 storage + cod")

@@ -111,8 +111,18 @@ def test_torch_tensors_resident_in_hbm_give_the_same_bits():
     assert np.array_equal(dev.z, host.z) and np.array_equal(dev.n_iter, host.n_iter)
     assert bs.LastKernelMilliseconds() > 0
     assert bs.AlgorithmicBytes() == 8 * nb * (60 * 60 + 38 * 60 + 4 * 60 + 38 + 4)
-    with pytest.raises(ValueError):
-        F.solve_tensors(bs, *[t.float() for t in tens])
+    with pytest.raises(ValueError):                                                    # mixed dtypes
+        F.solve_tensors(bs, tens[0].float(), *tens[1:])
+    # float32 tensors / arrays take the fp32-storage path: same bits as the widened float64 problem
+    t32 = [t.float() for t in tens]
+    F.solve_tensors(bs, *t32)
+    torch.cuda.synchronize()
+    dev32 = bs.GetSolution()
+    assert bs.AlgorithmicBytes() == nb * (4 * 6102 + 8 * 60)
+    bs.Solve(*[t.cpu().numpy() for t in t32]); host32 = bs.GetSolution()               # float32 numpy
+    bs.Solve(*[t.double().cpu().numpy() for t in t32]); wide = bs.GetSolution()        # widened float64
+    assert np.array_equal(dev32.z, wide.z) and np.array_equal(host32.z, wide.z)
+    assert np.array_equal(dev32.n_iter, wide.n_iter)
     ptrs = bs.device_pointers()
     assert ptrs["z"] != 0 and ptrs["n_iter"] != 0
 

@@ -91,12 +91,15 @@ class Solver:
         self.n, self.m, self.nc, self.s, self.batch = n, m, nc, s, batch
 
     def close(self):
-        if self.h:
-            self.L.fccqp_destroy(self.h)
-            self.h = C.c_void_p()
+        h, self.h = self.h, None
+        if h:
+            self.L.fccqp_destroy(h)
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
     def _ck(self, rc, what):
         if rc != OK:

@@ -295,7 +295,9 @@ __device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
 #pragma unroll
           for (int t = s; t < SLOTS; ++t) {
             const double l = M[cb + rowc[t]];
-            a[u][t] = (rlo[t] > k) ? l : 0.0;
+            // only the diagonal slot has rows <= k; slots below it are unmasked (their idle lanes
+            // accumulate garbage that the D step zeroes)
+            a[u][t] = (t == s) ? ((rlo[t] > k) ? l : 0.0) : l;
           }
           cb += col_step(k, N);                    // col_base(k + 1) - col_base(k)
         }
@@ -312,7 +314,7 @@ __device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
 #pragma unroll
         for (int t = s; t < SLOTS; ++t) {
           const double l = M[cb + rowc[t]];
-          x[t] = fma(-((rlo[t] > k) ? l : 0.0), xk, x[t]);
+          x[t] = fma(-((t == s) ? ((rlo[t] > k) ? l : 0.0) : l), xk, x[t]);
         }
         cb += col_step(k, N);
       }
@@ -335,7 +337,7 @@ __device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
 #pragma unroll
         for (int t = 0; t <= s; ++t) {
           const double l = M[cbl[t] + k];
-          x[t] = fma(-((rhi[t] < k) ? l : 0.0), xk, x[t]);
+          x[t] = fma(-((t == s) ? ((rhi[t] < k) ? l : 0.0) : l), xk, x[t]);   // slots above: all rows < k
         }
       }
       for (int kk0 = kend - rem - 1; kk0 >= 0; kk0 -= U) {
@@ -346,7 +348,7 @@ __device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
 #pragma unroll
           for (int t = 0; t <= s; ++t) {
             const double l = M[cbl[t] + k];
-            a[u][t] = (rhi[t] < k) ? l : 0.0;
+            a[u][t] = (t == s) ? ((rhi[t] < k) ? l : 0.0) : l;
           }
         }
 #pragma unroll

@@ -145,6 +145,19 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     e = fccqp::launch_fused(a, stream, qa_f32);
   } else {
     s->kernel_used = FCCQP_KERNEL_GENERIC;
+    if (!s->dwork && s->n > 0 && s->n <= 128) {
+      // LDS-resident shapes: per-instance staging for rho*G (n*n doubles), through which the
+      // generic kernel switches long-running instances from triangular sweeps to a mat-vec
+      // (fccqp_generic.hip); allocated on the first generic launch only
+      const size_t nn = (size_t)s->n * (size_t)s->n;
+      if (dmalloc(&s->dwork, (size_t)s->batch * nn) == hipSuccess) {
+        s->work_stride = (long long)nn;
+        a.workspace = s->dwork; a.workspace_stride = s->work_stride;
+      } else {
+        (void)hipGetLastError();   // no staging: the kernel keeps to the sweeps
+        s->dwork = nullptr;
+      }
+    }
     e = fccqp::launch_generic(a, s->lds_limit, stream, qa_f32);
   }
   if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "kernel launch", e);

@@ -88,7 +88,39 @@ __device__ __forceinline__ double fast_rcp(double d) {   // <= 1 ulp from the ro
   return r;
 }
 
+__device__ __forceinline__ double fast_rsqrt(double a) {  // a > 0; Newton twice on v_rsq_f64: <= 1-2 ulp
+  double r = __builtin_amdgcn_rsq(a);
+  double e = fma(-a * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  e = fma(-a * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  return r;
+}
+// reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25, for ONE component
+// v = f[comp] of the contact force (every lane of a contact triple calls it with the same
+// (fx, fy, fz)).  Same three branches, same f_z == 0 quirk; the side-of-cone branch evaluates
+// (r.f / r.r) r instead of normalising r first (:22-23), with v_rsq / v_rcp + Newton instead of the
+// IEEE sqrt / div sequences (same formulation as the fused kernel, fccqp_fused_impl.h).
+__device__ __forceinline__ double project_cone_component(double fx, double fy, double fz, double mu,
+                                                         double v, bool is_z) {
+  const double nxy2 = fx * fx + fy * fy;
+  const bool flat = !(nxy2 > 0.0);
+  const double rs = fast_rsqrt(flat ? 1.0 : nxy2);
+  const double nxy = flat ? 0.0 : nxy2 * rs;
+  const bool inside = mu * fz >= nxy;                   // :10-12
+  const bool polar = fz < -mu * nxy;                    // :15-17
+  const double ratio = mu * fz * rs;                    // :20
+  const double fz2 = fz * fz;
+  const double z2 = fma(ratio * ratio, nxy2, fz2);
+  const double dot = fma(ratio, nxy2, fz2);
+  const double sc = (z2 > 0.0) ? dot * fast_rcp(z2) : 0.0;   // zero ray: Eigen's normalize() no-op -> 0
+  const double side = sc * (is_z ? 1.0 : ratio) * v;
+  return inside ? v : (polar ? 0.0 : side);
+}
+
 constexpr int kPanel = 16;
+constexpr int kGSwitchIter = 16;       // ADMM iterations by triangular sweeps before G is built ...
+constexpr int kGSwitchIterMulti = 8;   // ... when four waves share the build (it is ~3x cheaper)
 using d2 = double __attribute__((ext_vector_type(2)));
 using lds_d2 = __attribute__((address_space(3))) d2;
 
@@ -362,6 +394,87 @@ __device__ void ldlt_solve(MP M, int N, int lane, double (&x)[SLOTS]) {
   }
 }
 
+// R right-hand sides at once through the same factorisation (matrix in LDS): X[r][t] is entry
+// lane + 64 t of right-hand side r.  The L operands of a step are loaded once and applied to all R
+// vectors (per vector: one v_readlane pair + one FMA per live slot), which is what makes building
+// G = (K_rho^-1)[0:n,0:n] affordable (see the ADMM loop).  kstart: every right-hand side is zero
+// above row kstart, so the forward sweep starts there.
+template <int SLOTS, int R>
+__device__ void ldlt_solve_multi(const lds_f64 *M, const int N, const int lane, double (&X)[R][SLOTS],
+                                 const int kstart) {
+  int rowc[SLOTS], cbl[SLOTS], rlo[SLOTS], rhi[SLOTS];
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const int i = lane + kWave * t;
+    rowc[t] = (i < N) ? i : N - 1;
+    rlo[t] = (i < N) ? i : -1;
+    rhi[t] = (i < N) ? i : 0x7fffffff;
+    cbl[t] = col_base(rowc[t], N);
+  }
+  // ---- forward ----------------------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int kend = (N - s * kWave < kWave) ? N - s * kWave : kWave;
+    int kk = kstart - s * kWave;
+    kk = (kk < 0) ? 0 : kk;
+    if (kk < kend) {
+      int cb = col_base(s * kWave + kk, N);
+      double an[SLOTS];
+#pragma unroll
+      for (int t = s; t < SLOTS; ++t) an[t] = M[cb + rowc[t]];
+      for (; kk < kend; ++kk) {
+        const int k = s * kWave + kk;
+        double ac[SLOTS];
+#pragma unroll
+        for (int t = s; t < SLOTS; ++t) ac[t] = (t == s) ? ((rlo[t] > k) ? an[t] : 0.0) : an[t];
+        cb += col_step(k, N);
+        const int cbn = (kk + 1 < kend) ? cb : cb - col_step(k, N);   // next step's column (or a re-read)
+#pragma unroll
+        for (int t = s; t < SLOTS; ++t) an[t] = M[cbn + rowc[t]];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double xk = lane_bcast(X[r][s], kk);
+#pragma unroll
+          for (int t = s; t < SLOTS; ++t) X[r][t] = fma(-ac[t], xk, X[r][t]);
+        }
+      }
+    }
+  }
+  // ---- D^-1 with the pseudo-inverse rule --------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    const double d = M[cbl[t] + rowc[t]];
+    const double rinv = (rlo[t] >= 0 && fabs(d) > DBL_MIN) ? 1.0 / d : 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) X[r][t] *= rinv;
+  }
+  // ---- backward ---------------------------------------------------------------------------------
+#pragma unroll
+  for (int s = SLOTS - 1; s >= 0; --s) {
+    const int kend = (N - s * kWave < kWave) ? N - s * kWave : kWave;
+    if (kend > 0) {
+      double an[SLOTS];
+#pragma unroll
+      for (int t = 0; t <= s; ++t) an[t] = M[cbl[t] + s * kWave + kend - 1];
+      for (int kk = kend - 1; kk >= 0; --kk) {
+        const int k = s * kWave + kk;
+        double ac[SLOTS];
+#pragma unroll
+        for (int t = 0; t <= s; ++t) ac[t] = (t == s) ? ((rhi[t] < k) ? an[t] : 0.0) : an[t];
+        const int kn = (kk > 0) ? k - 1 : k;
+#pragma unroll
+        for (int t = 0; t <= s; ++t) an[t] = M[cbl[t] + kn];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double xk = lane_bcast(X[r][s], kk);
+#pragma unroll
+          for (int t = 0; t <= s; ++t) X[r][t] = fma(-ac[t], xk, X[r][t]);
+        }
+      }
+    }
+  }
+}
+
 // reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25
 __device__ __forceinline__ void project_cone3(double fx, double fy, double fz, double mu,
                                               double &ox, double &oy, double &oz) {
@@ -377,6 +490,77 @@ __device__ __forceinline__ void project_cone3(double fx, double fy, double fz, d
   }
   const double dot = rx * fx + ry * fy + rz * fz;                  // :23
   ox = dot * rx; oy = dot * ry; oz = dot * rz;
+}
+
+// ---- building rho*G with several waves ----------------------------------------------------------
+// Shapes that need three or four register slots own a whole CU's LDS (one workgroup per CU), so
+// their workgroup is launched with four waves, one per SIMD: wave 0 runs the solver, waves 1-3
+// wait at a barrier and are only called on for the one step that parallelises trivially -- the
+// n + 1 substitutions that build G, split by batches of RB right-hand sides -- and for the copy of
+// G into LDS.  Commands go through one LDS word.
+template <int SLOTS, bool MAT_IN_LDS>
+constexpr int waves_for() { return (MAT_IN_LDS && SLOTS >= 3 && SLOTS <= 4) ? 4 : 1; }
+template <int SLOTS>
+constexpr int g_batch() { return (SLOTS <= 3) ? 16 : 8; }   // right-hand sides per substitution batch
+constexpr int kCmdBuild = 1, kCmdDone = 2;
+
+__device__ __forceinline__ lds_f64 *ctrl_word(double *lds, int N, int nc) {
+  return (lds_f64 *)lds + packed_doubles(N) + nc + 2 + kPanel;
+}
+
+// One batch: right-hand side index j = j0 + r - 1; j == -1 is [-b; b_eq] (WITH_RHS only, batch 0),
+// j >= 0 the unit vector e_j.  Stores rho * (solution rows < n) as column j of the staging matrix.
+template <int SLOTS, int RB, bool WITH_RHS>
+__device__ __forceinline__ void g_build_batch(const lds_f64 *M, const int N, const int n, const int lane,
+                                              const int j0, const double rho, double *stage,
+                                              const double *vb, const double *vtail, double *xc) {
+  constexpr int GS = (SLOTS < 2) ? SLOTS : 2;
+  double X[RB][SLOTS];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int j = j0 + r - 1;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const int i = lane + kWave * t;
+      double v = (i == j && j < n) ? 1.0 : 0.0;
+      if constexpr (WITH_RHS) { if (j < 0) v = (i < n) ? -vb[t] : vtail[t]; }
+      X[r][t] = v;
+    }
+  }
+  ldlt_solve_multi<SLOTS, RB>(M, N, lane, X, (j0 == 0) ? 0 : j0 - 1);
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int j = j0 + r - 1;
+#pragma unroll
+    for (int t = 0; t < GS; ++t) {
+      const int i = lane + kWave * t;
+      if constexpr (WITH_RHS) { if (j < 0) xc[t] = (i < n) ? X[r][t] : 0.0; }
+      if (j >= 0 && j < n && i < n) stage[(size_t)j * n + i] = rho * X[r][t];
+    }
+  }
+}
+
+// waves 1..WAVES-1 of a multi-wave workgroup, for one instance
+template <int SLOTS, int WAVES>
+__device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, const int wave, const int lane) {
+  constexpr int RB = g_batch<SLOTS>();
+  const int n = a.n, N = a.n + a.m;
+  lds_f64 *M = (lds_f64 *)lds;
+  volatile lds_f64 *ctrl = ctrl_word(lds, N, a.nc);
+  for (;;) {
+    __syncthreads();                                   // A: a command is posted
+    if ((int)ctrl[0] == kCmdDone) break;
+    double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
+    for (int b = wave; b * RB <= n; b += WAVES)
+      g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();                                   // B: every column of G is staged, L is dead
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int total = n * n;
+#pragma unroll 8
+    for (int e = wave * kWave + lane; e < total; e += WAVES * kWave) M[e] = stage[e];
+    __syncthreads();                                   // C: G is in LDS
+  }
 }
 
 // Solves instance `inst`.  x0_given: the presolve was done elsewhere (fallback pass): x0 comes from
@@ -520,22 +704,149 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     double xbar[SLOTS], lcbar[SLOTS];
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) { xbar[t] = x[t]; lcbar[t] = x[t]; }  // :74-75
+    // per-lane constants of the projections, and the last residuals (for the reported norms)
+    int cidx[SLOTS], ccomp[SLOTS];
+    double vmu[SLOTS], xr_last[SLOTS], lr_last[SLOTS];
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const int i = lane + kWave * t;
+      cidx[t] = is_cone[t] ? (i - s0) / 3 : 0;
+      ccomp[t] = is_cone[t] ? (i - s0) - 3 * cidx[t] : 0;
+      vmu[t] = is_cone[t] ? mu[cidx[t]] : 0.0;
+      xr_last[t] = 0.0; lr_last[t] = 0.0;
+    }
+
+    // The first kGSwitchIter iterations solve the KKT system by two triangular sweeps, like the
+    // reference (:83-87).  An instance still running after that gets the explicit operator
+    //   x = x_c + (rho G) w,   G = (K_rho^-1)[0:n,0:n],  x_c = (K_rho^-1 [-b; b_eq])[0:n],
+    //   w = x_bar - mu_x (contact segment: lambda_c_bar - mu_lambda_c)          -- same solve, :81-87
+    // built by n + 1 simultaneous substitutions (ldlt_solve_multi), staged through a.workspace and
+    // copied into LDS over L, which is not needed any more: an iteration becomes an n x n mat-vec
+    // (~15x fewer instructions than the sweeps at N = 174).  Building G costs about 30 sweep
+    // iterations, so it is only done for instances that have already shown they iterate.
+    constexpr int GS = (SLOTS < 2) ? SLOTS : 2;        // register slots that hold variables (n <= 128)
+    constexpr int RB = g_batch<SLOTS>();
+    constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
+    const int gswitch = (WAVES > 1) ? kGSwitchIterMulti : kGSwitchIter;
+    const int g_off = 0, w_off = (n * n + 1) & ~1;     // LDS doubles: rho*G [n][n] (column-major), w [w_len]
+    const int w_len = 6 * (((n + 1) / 2 + 2) / 3 + 2); // w zero-padded for the chunked mat-vec (3 pairs per chunk)
+    bool use_g = false, g_ready = false;
+    if constexpr (MAT_IN_LDS && SLOTS <= 4) {
+      use_g = a.workspace != nullptr && n <= 2 * kWave && n > 0 && w_off + w_len <= npack &&
+              a.workspace_stride >= (long long)n * n;
+    }
+    double xc[GS];
+#pragma unroll
+    for (int t = 0; t < GS; ++t) xc[t] = 0.0;
 
     n_iter = a.max_iter;                               // :78
     for (int iter = 0; iter < a.max_iter; ++iter) {
-      double r[SLOTS];
-#pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int i = lane + kWave * t;
-        double q = -a.rho * (xbar[t] - mux[t]);                    // :81
-        if (is_cone[t]) q = -a.rho * (lcbar[t] - mulc[t]);          // :82 overwrites the segment
-        r[t] = (i < n) ? -(vb[t] + q) : vtail[t];                   // :83
+      if constexpr (MAT_IN_LDS && SLOTS <= 4) {
+        if (use_g && iter == gswitch) {
+          double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
+          if constexpr (WAVES > 1) {
+            if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdBuild;
+            __syncthreads();                           // A (see helper_wave)
+          }
+          g_build_batch<SLOTS, RB, true>(M, N, n, lane, 0, a.rho, stage, vb, vtail, xc);
+          for (int b = WAVES; b * RB <= n; b += WAVES)
+            g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
+          // the staged columns are read back by other lanes (and waves)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          if constexpr (WAVES > 1) __syncthreads();    // B
+          else wave_sync();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          const int total = n * n;
+#pragma unroll 8
+          for (int e = lane; e < total; e += WAVES * kWave) M[g_off + e] = stage[e];
+          if constexpr (WAVES > 1) __syncthreads();    // C
+          else wave_sync();
+          g_ready = true;
+        }
       }
-      ldlt_solve<SLOTS, MP>(M, N, lane, r);                             // :86
+      if (g_ready) {
+        if constexpr (MAT_IN_LDS && SLOTS <= 4) {
+          lds_f64 *wbuf = M + w_off;
+          int rc2[GS];
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int i = lane + kWave * t;
-        x[t] = (i < n) ? r[t] : 0.0;                                // :87
+          for (int t = 0; t < GS; ++t) {
+            const int i = lane + kWave * t;
+            rc2[t] = (i < n) ? i : n - 1;
+            if (i < n) wbuf[i] = is_cone[t] ? (lcbar[t] - mulc[t]) : (xbar[t] - mux[t]);
+          }
+          // zero pad up to a whole number of chunks (g_ok checked the room): padded pairs multiply a
+          // clamped, valid column of G by w = 0
+          constexpr int CH = 3;                        // column pairs per chunk: 3 + 12 loads <= 15 (lgkmcnt)
+          const int npair = (n + 1) / 2, nchunk = (npair + CH - 1) / CH;
+          for (int i = n + lane; i < 2 * CH * (nchunk + 2); i += kWave) wbuf[i] = 0.0;   // == w_len
+          wave_sync();
+          double acc0[GS], acc1[GS];
+#pragma unroll
+          for (int t = 0; t < GS; ++t) { acc0[t] = xc[t]; acc1[t] = 0.0; }
+          const lds_d2 *w2 = reinterpret_cast<const lds_d2 *>(wbuf);
+          // Left alone the compiler serialises this loop (one load, one wait, one FMA, same
+          // register); the operands of a whole chunk are loaded into distinct registers first, and
+          // the next chunk's loads are issued before this chunk's FMAs.
+          struct Chunk { d2 w[CH]; double ga[CH][GS], gb[CH][GS]; };
+          auto fetch = [&](const int c, Chunk &o) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+              const int jp = c * CH + u;
+              o.w[u] = w2[jp];
+              const int j0 = (2 * jp < n) ? 2 * jp : n - 1, j1 = (2 * jp + 1 < n) ? 2 * jp + 1 : n - 1;
+#pragma unroll
+              for (int t = 0; t < GS; ++t) {
+                o.ga[u][t] = M[g_off + j0 * n + rc2[t]];
+                o.gb[u][t] = M[g_off + j1 * n + rc2[t]];
+              }
+            }
+          };
+          auto apply = [&](const Chunk &o) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+#pragma unroll
+              for (int t = 0; t < GS; ++t) {
+                acc0[t] = fma(o.ga[u][t], o.w[u].x, acc0[t]);
+                acc1[t] = fma(o.gb[u][t], o.w[u].y, acc1[t]);
+              }
+            }
+          };
+          Chunk ca, cb;
+          fetch(0, ca);
+#pragma nounroll
+          for (int c = 0; c < nchunk; c += 2) {
+            fetch(c + 1, cb);                          // c + 1 <= nchunk: at worst an all-padding chunk
+            __builtin_amdgcn_sched_barrier(0);
+            apply(ca);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(c + 2, ca);                          // may also be padding (w zero-filled to nchunk + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            apply(cb);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int t = 0; t < SLOTS; ++t) x[t] = 0.0;
+#pragma unroll
+          for (int t = 0; t < GS; ++t) {
+            const int i = lane + kWave * t;
+            x[t] = (i < n) ? acc0[t] + acc1[t] : 0.0;
+          }
+        }
+      } else {
+        double r[SLOTS];
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+          const int i = lane + kWave * t;
+          double q = -a.rho * (xbar[t] - mux[t]);                    // :81
+          if (is_cone[t]) q = -a.rho * (lcbar[t] - mulc[t]);          // :82 overwrites the segment
+          r[t] = (i < n) ? -(vb[t] + q) : vtail[t];                   // :83
+        }
+        ldlt_solve<SLOTS, MP>(M, N, lane, r);                             // :86
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+          const int i = lane + kWave * t;
+          x[t] = (i < n) ? r[t] : 0.0;                                // :87
+        }
       }
       // slack update :90-92
       wave_sync();
@@ -545,41 +856,53 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
         if (is_cone[t]) cone_buf[i - s0] = x[t] + mulc[t];
       }
       wave_sync();
-      double xr_max = -HUGE_VAL, xr_min = HUGE_VAL, lr_max = -HUGE_VAL, lr_min = HUGE_VAL;
 #pragma unroll
       for (int t = 0; t < SLOTS; ++t) {
         const int i = lane + kWave * t;
+        xr_last[t] = 0.0; lr_last[t] = 0.0;
         if (i < n) {
           const double v = x[t] + mux[t];
           const double tt = (vub[t] < v) ? vub[t] : v;   // std::min(x, ub)
           xbar[t] = (tt < vlb[t]) ? vlb[t] : tt;         // std::max(., lb)  constraint_utils.cpp:43
-          const double xr = x[t] - xbar[t];               // :95
-          xr_max = (xr_max < xr) ? xr : xr_max;
-          xr_min = (xr < xr_min) ? xr : xr_min;
-          mux[t] += xr;                                   // :101
+          xr_last[t] = x[t] - xbar[t];                    // :95
+          mux[t] += xr_last[t];                           // :101
         }
         if (is_cone[t]) {
-          const int c = (i - s0) / 3, comp = (i - s0) - 3 * c;
-          double ox, oy, oz;
-          project_cone3(cone_buf[3 * c], cone_buf[3 * c + 1], cone_buf[3 * c + 2], mu[c], ox, oy, oz);
-          lcbar[t] = (comp == 0) ? ox : ((comp == 1) ? oy : oz);
-          const double lr = x[t] - lcbar[t];              // :96
-          lr_max = (lr_max < lr) ? lr : lr_max;
-          lr_min = (lr < lr_min) ? lr : lr_min;
-          mulc[t] += lr;                                  // :102
+          const int base = 3 * cidx[t];
+          lcbar[t] = project_cone_component(cone_buf[base], cone_buf[base + 1], cone_buf[base + 2], vmu[t],
+                                            x[t] + mulc[t], ccomp[t] == 2);
+          lr_last[t] = x[t] - lcbar[t];                   // :96
+          mulc[t] += lr_last[t];                          // :102
         }
       }
-      // :97-98  abs(max(maxCoeff, -minCoeff)); empty contact set defined as 0
-      {
-        const double mx = wave_max(xr_max), mn = wave_min(xr_min);
-        x_res_norm = (n > 0) ? fabs((mx < -mn) ? -mn : mx) : 0.0;
-        const double cmx = wave_max(lr_max), cmn = wave_min(lr_min);
-        lc_res_norm = (nc > 0) ? fabs((cmx < -cmn) ? -cmn : cmx) : 0.0;
+      // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps: one ballot per iteration
+      // instead of four wave reductions; the norms themselves (:97-98) are only reported and are
+      // reduced once after the loop.  An empty contact set has norm 0.
+      bool ok = true;
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = lane + kWave * t;
+        if (i < n) ok = ok && (fabs(xr_last[t]) < a.eps_bound);
+        if (is_cone[t]) ok = ok && (fabs(lr_last[t]) < a.eps_fcone);
       }
-      if (lc_res_norm < a.eps_fcone && x_res_norm < a.eps_bound) {  // :105-109
+      if (nc == 0) ok = ok && (0.0 < a.eps_fcone);
+      if (n == 0) ok = ok && (0.0 < a.eps_bound);
+      if (__all(ok)) {
         n_iter = iter;
         break;
       }
+    }
+    if (a.max_iter > 0) {
+      // :97-98  abs(max(maxCoeff, -minCoeff)) == max_i |r_i| of the last iteration executed
+      double xm = 0.0, lm = 0.0;
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) {
+        const double ax = fabs(xr_last[t]), al = fabs(lr_last[t]);
+        xm = (xm < ax) ? ax : xm;
+        lm = (lm < al) ? al : lm;
+      }
+      x_res_norm = wave_max(xm);
+      lc_res_norm = wave_max(lm);
     }
   }
 
@@ -630,18 +953,29 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
 }
 
 template <int SLOTS, bool MAT_IN_LDS, class TIN>
-__global__ __launch_bounds__(kWave) void generic_kernel(const KernelArgs a) {
+__global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  // wave 0 runs the solver (all of it when WAVES == 1); see helper_wave for the others
+  auto run = [&](const int inst, const bool from_list) {
+    if (wave == 0) {
+      if (from_list) cod::cod_presolve<TIN>(a, inst, a.cod_ws + (long long)blockIdx.x * a.cod_stride);   // fcc_qp.cpp:165,176
+      solve_instance<SLOTS, MAT_IN_LDS, TIN>(a, lds, inst, from_list);
+      if constexpr (WAVES > 1) {
+        if (lane == 0) ctrl_word(lds, a.n + a.m, a.nc)[0] = (double)kCmdDone;
+        __syncthreads();
+      }
+    } else {
+      if constexpr (WAVES > 1) helper_wave<SLOTS, WAVES>(a, lds, inst, wave, lane);
+    }
+  };
   if (a.inst_list) {  // list mode (fallback launch): persistent blocks walk the fallback list
     const int total = *a.inst_count;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_count = 0;
-    for (int li = blockIdx.x; li < total; li += gridDim.x) {
-      const int inst = a.inst_list[li];
-      cod::cod_presolve<TIN>(a, inst, a.cod_ws + (long long)blockIdx.x * a.cod_stride);   // fcc_qp.cpp:165,176
-      solve_instance<SLOTS, MAT_IN_LDS, TIN>(a, lds, inst, true);
-    }
+    for (int li = blockIdx.x; li < total; li += gridDim.x) run(a.inst_list[li], true);
   } else if ((int)blockIdx.x < a.batch) {
-    solve_instance<SLOTS, MAT_IN_LDS, TIN>(a, lds, (int)blockIdx.x, false);
+    run((int)blockIdx.x, false);
   }
 }
 
@@ -650,6 +984,7 @@ inline int slots_for(int N) { return (N + kWave - 1) / kWave; }
 template <int SLOTS, class TIN>
 hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, int blocks, hipStream_t stream) {
   dim3 grid(blocks), block(kWave);
+  if (mat_in_lds) block = dim3(kWave * waves_for<(SLOTS > 4 ? 4 : SLOTS), true>());
   if constexpr (SLOTS > 4) {
     if (mat_in_lds) return hipErrorInvalidValue;   // N > 256 never fits the 160 KiB LDS
   }
@@ -684,7 +1019,8 @@ hipError_t launch_widen(const float *src, double *dst, size_t count, hipStream_t
 size_t generic_lds_bytes(int n, int m, int nc) {
   const size_t N = (size_t)n + m;
   // + one panel of slack: the last panel's broadcast reads run up to 15 rows past the matrix
-  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel);
+  // + 2 for the command word of the multi-wave workgroups (ctrl_word)
+  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel + 2);
 }
 
 long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {

@@ -7,7 +7,7 @@ from tests import capi as C
 for shape, name, nb in [(P.LARGE, "large", 4096), (P.WALKING, "walking-generic", 4096)]:
     B = P.workload("W-sat", nb, shape, distinct=64)
     s = C.Solver(*shape.ctor_args, batch=nb); s.set_kernel(C.KERNEL_GENERIC)
-    for it in (0, 10, 100):
+    for it in (0, 16, 17, 58, 100):
         opt = dict(P.HARNESS_OPTIONS); opt["max_iter"] = it
         s.set_options(**opt)
         for rep in range(2):

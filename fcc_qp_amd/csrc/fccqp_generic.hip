@@ -492,6 +492,46 @@ __device__ __forceinline__ void project_cone3(double fx, double fy, double fz, d
   ox = dot * rx; oy = dot * ry; oz = dot * rz;
 }
 
+// Assembly of the packed lower KKT [[Q + rho I, .],[A, 0]] (fcc_qp.cpp:146-150), the share of wave
+// `part` of `parts`.  Row-wise: lanes run along a row of Q (then A), so global reads are coalesced,
+// and the loads of eight rows are issued before the first store.  Only the lower triangle of Q is
+// kept (what Eigen's LDLT reads).  Loads are unconditional on clamped addresses; the mask only
+// gates stores.  MP: LDS or global pointer to the matrix.
+template <class TIN, class MP>
+__device__ __forceinline__ void assemble_share(MP M, const TIN *Q, const TIN *A, const int n, const int N,
+                                               const double rho, const int lane, const int part,
+                                               const int parts) {
+  constexpr int R = 8;
+  const int jc_hi = (n > 0) ? n - 1 : 0;
+  if (n > 0) {
+    for (int i0 = R * part; i0 < N; i0 += R * parts) {
+      const int ilast = (i0 + R - 1 < N) ? i0 + R - 1 : N - 1;
+      const int jend = (ilast < n) ? ilast + 1 : n;          // columns needed by this row group
+      for (int j0 = 0; j0 < jend; j0 += kWave) {
+        const int j = j0 + lane;
+        const int jc = (j < jc_hi) ? j : jc_hi;
+        double v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int i = (i0 + r < N) ? i0 + r : N - 1;
+          const TIN *src = (i < n) ? Q + (size_t)i * n : A + (size_t)(i - n) * n;
+          v[r] = (double)src[jc];
+        }
+        const int cj = col_base(jc, N);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int i = i0 + r;
+          if (i < N && j < n && j <= i) M[cj + i] = v[r] + ((i == j) ? rho : 0.0);
+        }
+      }
+    }
+  }
+  for (int j = n + part; j < N; j += parts) {                  // zero block (rows and columns >= n)
+    const int cj = col_base(j, N);
+    for (int i = j + lane; i < N; i += kWave) M[cj + i] = 0.0;
+  }
+}
+
 // ---- building rho*G with several waves ----------------------------------------------------------
 // Shapes that need three or four register slots own a whole CU's LDS (one workgroup per CU), so
 // their workgroup is launched with four waves, one per SIMD: wave 0 runs the solver, waves 1-3
@@ -502,7 +542,7 @@ template <int SLOTS, bool MAT_IN_LDS>
 constexpr int waves_for() { return (MAT_IN_LDS && SLOTS >= 3 && SLOTS <= 4) ? 4 : 1; }
 template <int SLOTS>
 constexpr int g_batch() { return (SLOTS <= 3) ? 16 : 8; }   // right-hand sides per substitution batch
-constexpr int kCmdBuild = 1, kCmdDone = 2;
+constexpr int kCmdBuild = 1, kCmdDone = 2, kCmdAssemble = 3;
 
 __device__ __forceinline__ lds_f64 *ctrl_word(double *lds, int N, int nc) {
   return (lds_f64 *)lds + packed_doubles(N) + nc + 2 + kPanel;
@@ -541,7 +581,7 @@ __device__ __forceinline__ void g_build_batch(const lds_f64 *M, const int N, con
 }
 
 // waves 1..WAVES-1 of a multi-wave workgroup, for one instance
-template <int SLOTS, int WAVES>
+template <int SLOTS, int WAVES, class TIN>
 __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, const int wave, const int lane) {
   constexpr int RB = g_batch<SLOTS>();
   const int n = a.n, N = a.n + a.m;
@@ -549,7 +589,15 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
   volatile lds_f64 *ctrl = ctrl_word(lds, N, a.nc);
   for (;;) {
     __syncthreads();                                   // A: a command is posted
-    if ((int)ctrl[0] == kCmdDone) break;
+    const int cmd = (int)ctrl[0];
+    if (cmd == kCmdDone) break;
+    if (cmd == kCmdAssemble) {
+      const TIN *Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
+      const TIN *A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * a.m * n;
+      assemble_share<TIN>(M, Q, A, n, N, (double)ctrl[1], lane, wave, WAVES);
+      __syncthreads();                                 // B: the matrix is complete
+      continue;
+    }
     double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
     for (int b = wave; b * RB <= n; b += WAVES)
       g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
@@ -619,40 +667,19 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   long long ticks = 0;
 
   // ---- assemble the packed lower KKT (fcc_qp.cpp:146-150) --------------------------------
-  // Row-wise: lanes run along a row of Q (then A), so global reads are coalesced, and the loads of
-  // eight rows are issued before the first LDS store.  Only the lower triangle of Q is kept (what
-  // Eigen's LDLT reads).  Loads are unconditional on clamped addresses; the mask only gates stores.
   auto assemble = [&](double rho) {
-    constexpr int R = 8;
-    const int jc_hi = (n > 0) ? n - 1 : 0;
-    if (n > 0) {
-      for (int i0 = 0; i0 < N; i0 += R) {
-        const int ilast = (i0 + R - 1 < N) ? i0 + R - 1 : N - 1;
-        const int jend = (ilast < n) ? ilast + 1 : n;          // columns needed by this row group
-        for (int j0 = 0; j0 < jend; j0 += kWave) {
-          const int j = j0 + lane;
-          const int jc = (j < jc_hi) ? j : jc_hi;
-          double v[R];
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int i = (i0 + r < N) ? i0 + r : N - 1;
-            const TIN *src = (i < n) ? Q + (size_t)i * n : A + (size_t)(i - n) * n;
-            v[r] = (double)src[jc];
-          }
-          const int cj = col_base(jc, N);
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int i = i0 + r;
-            if (i < N && j < n && j <= i) M[cj + i] = v[r] + ((i == j) ? rho : 0.0);
-          }
-        }
-      }
+    constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
+    if constexpr (WAVES > 1) {
+      // all four waves fetch (the lone wave would otherwise sit through ~40 dependent HBM round trips)
+      lds_f64 *ctrl = ctrl_word(lds, N, nc);
+      if (lane == 0) { ctrl[0] = (double)kCmdAssemble; ctrl[1] = rho; }
+      __syncthreads();                                 // A (see helper_wave)
+      assemble_share<TIN>(M, Q, A, n, N, rho, lane, 0, WAVES);
+      __syncthreads();                                 // B
+    } else {
+      assemble_share<TIN>(M, Q, A, n, N, rho, lane, 0, 1);
+      wave_sync();
     }
-    for (int j = n; j < N; ++j) {                              // zero block (rows and columns >= n)
-      const int cj = col_base(j, N);
-      for (int i = j + lane; i < N; i += kWave) M[cj + i] = 0.0;
-    }
-    wave_sync();
   };
 
   // ---- presolve (fcc_qp.cpp:159-178): skipped on warm start unless equality-only ---------
@@ -967,7 +994,7 @@ __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void gene
         __syncthreads();
       }
     } else {
-      if constexpr (WAVES > 1) helper_wave<SLOTS, WAVES>(a, lds, inst, wave, lane);
+      if constexpr (WAVES > 1) helper_wave<SLOTS, WAVES, TIN>(a, lds, inst, wave, lane);
     }
   };
   if (a.inst_list) {  // list mode (fallback launch): persistent blocks walk the fallback list
@@ -1019,7 +1046,7 @@ hipError_t launch_widen(const float *src, double *dst, size_t count, hipStream_t
 size_t generic_lds_bytes(int n, int m, int nc) {
   const size_t N = (size_t)n + m;
   // + one panel of slack: the last panel's broadcast reads run up to 15 rows past the matrix
-  // + 2 for the command word of the multi-wave workgroups (ctrl_word)
+  // + 2 for the command words of the multi-wave workgroups (ctrl_word)
   return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel + 2);
 }
 

@@ -14,4 +14,5 @@ for shape, name, nb in [(P.LARGE, "large", 4096), (P.WALKING, "walking-generic",
             s.solve_ok(*B.arrays()); ms = s.kernel_ms()
         z, d = s.solution()
         print(name, "max_iter", it, "kernel ms %.3f" % ms, "-> %.0f solves/s" % (nb / ms * 1e3),
-              "; mean n_iter", np.mean([x.n_iter for x in d]), flush=True)
+              "; mean n_iter", np.mean([x.n_iter for x in d]),
+              "; factorisations %.1f us/QP" % (1e6 * np.mean([x.factorization_time for x in d])), flush=True)

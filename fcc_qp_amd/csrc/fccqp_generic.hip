@@ -133,8 +133,15 @@ using lds_d2 = __attribute__((address_space(3))) d2;
 // (c) factorise the 16x16 diagonal block and the rows below it with the multipliers read out of
 // the owner lanes (v_readlane), (d) one write-back.  The diagonal slot keeps d (the solve applies
 // Eigen's pseudo-inverse rule).  Returns true on a zero / non-finite pivot.
-template <int SLOTS, int SD>
-__device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int lane, const int c0) {
+//
+// COOP: the panels of one factorisation are dealt round-robin to the waves of a multi-wave
+// workgroup (ldlt_factor_share).  Panel p needs the finished columns of panels 0..p-1: `done`
+// (an LDS word) counts the finished panels, the bulk update is applied one earlier panel at a time
+// as soon as that panel is published, and the panel publishes itself at the end.  Owners of lower
+// panels never wait on higher ones, so the waits always terminate.
+template <int SLOTS, int SD, bool COOP>
+__device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int lane, const int c0,
+                                           volatile lds_f64 *done) {
   constexpr int P = kPanel, NT = SLOTS - SD;
   int rc[NT];
 #pragma unroll
@@ -170,12 +177,13 @@ __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int la
       }
     }
   };
-  if (c0 > 0) {                                              // c0 is a multiple of 16: q, q+1 < c0
+  // columns [q0, q1) of earlier panels, q0 and q1 multiples of 16 (so q, q+1 are always both < q1)
+  auto bulk = [&](const int q0, const int q1) {
     Ops oa, ob;
-    int cb = col_base(0, N);
-    fetch(cb, 0, oa);
+    int cb = col_base(q0, N);
+    fetch(cb, q0, oa);
 #pragma nounroll
-    for (int q = 0; q < c0; q += 2) {
+    for (int q = q0; q < q1; q += 2) {
       cb += col_step(q, N);
       fetch(cb, q + 1, ob);
       apply(oa);
@@ -183,6 +191,16 @@ __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int la
       fetch(cb, (q + 2 < N) ? q + 2 : q + 1, oa);            // one past the end on the last trip: unused
       apply(ob);
     }
+  };
+  if constexpr (COOP) {
+#pragma nounroll
+    for (int q0 = 0; q0 < c0; q0 += P) {
+      while ((int)done[0] < q0 / P + 1) __builtin_amdgcn_s_sleep(1);   // panel q0/16 published?
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      bulk(q0, q0 + P);
+    }
+  } else {
+    if (c0 > 0) bulk(0, c0);
   }
   const int lane0 = c0 & (kWave - 1);
   const int rel = lane - lane0;
@@ -237,6 +255,10 @@ __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int la
     M[col_base(rowd, N) + rowd] = dmine;
   }
   wave_sync();
+  if constexpr (COOP) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the panel's columns before the count
+    if (lane == 0) done[0] = (double)(c0 / P + 1);
+  }
   return bad_any;
 }
 
@@ -247,10 +269,26 @@ __device__ bool ldlt_factor(lds_f64 *M, int N, int lane) {
 #pragma nounroll
   for (int c0 = 0; c0 < N; c0 += kPanel) {
     const int sd = c0 >> 6;
-    if (sd == 0) bad |= ldlt_panel<SLOTS, 0>(M, N, lane, c0);
-    if constexpr (SLOTS > 1) { if (sd == 1) bad |= ldlt_panel<SLOTS, 1>(M, N, lane, c0); }
-    if constexpr (SLOTS > 2) { if (sd == 2) bad |= ldlt_panel<SLOTS, 2>(M, N, lane, c0); }
-    if constexpr (SLOTS > 3) { if (sd == 3) bad |= ldlt_panel<SLOTS, 3>(M, N, lane, c0); }
+    if (sd == 0) bad |= ldlt_panel<SLOTS, 0, false>(M, N, lane, c0, nullptr);
+    if constexpr (SLOTS > 1) { if (sd == 1) bad |= ldlt_panel<SLOTS, 1, false>(M, N, lane, c0, nullptr); }
+    if constexpr (SLOTS > 2) { if (sd == 2) bad |= ldlt_panel<SLOTS, 2, false>(M, N, lane, c0, nullptr); }
+    if constexpr (SLOTS > 3) { if (sd == 3) bad |= ldlt_panel<SLOTS, 3, false>(M, N, lane, c0, nullptr); }
+  }
+  return bad;
+}
+
+// The panels part, part + parts, ... of a factorisation shared by `parts` waves (see ldlt_panel).
+template <int SLOTS>
+__device__ bool ldlt_factor_share(lds_f64 *M, int N, int lane, int part, int parts, volatile lds_f64 *done) {
+  static_assert(SLOTS <= 4, "a matrix that fits in LDS has N <= 256");
+  bool bad = false;
+#pragma nounroll
+  for (int c0 = part * kPanel; c0 < N; c0 += parts * kPanel) {
+    const int sd = c0 >> 6;
+    if (sd == 0) bad |= ldlt_panel<SLOTS, 0, true>(M, N, lane, c0, done);
+    if constexpr (SLOTS > 1) { if (sd == 1) bad |= ldlt_panel<SLOTS, 1, true>(M, N, lane, c0, done); }
+    if constexpr (SLOTS > 2) { if (sd == 2) bad |= ldlt_panel<SLOTS, 2, true>(M, N, lane, c0, done); }
+    if constexpr (SLOTS > 3) { if (sd == 3) bad |= ldlt_panel<SLOTS, 3, true>(M, N, lane, c0, done); }
   }
   return bad;
 }
@@ -542,7 +580,10 @@ template <int SLOTS, bool MAT_IN_LDS>
 constexpr int waves_for() { return (MAT_IN_LDS && SLOTS >= 3 && SLOTS <= 4) ? 4 : 1; }
 template <int SLOTS>
 constexpr int g_batch() { return (SLOTS <= 3) ? 16 : 8; }   // right-hand sides per substitution batch
-constexpr int kCmdBuild = 1, kCmdDone = 2, kCmdAssemble = 3;
+constexpr int kCmdBuild = 1, kCmdDone = 2, kCmdAssemble = 3, kCmdFactor = 4;
+// command words (doubles after the panel slack): [0] command, [1] rho, [2] finished-panel count of a
+// shared factorisation, [3 + wave] that wave's bad-pivot flag
+constexpr int kCtrlWords = 8;
 
 __device__ __forceinline__ lds_f64 *ctrl_word(double *lds, int N, int nc) {
   return (lds_f64 *)lds + packed_doubles(N) + nc + 2 + kPanel;
@@ -596,6 +637,12 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       const TIN *A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * a.m * n;
       assemble_share<TIN>(M, Q, A, n, N, (double)ctrl[1], lane, wave, WAVES);
       __syncthreads();                                 // B: the matrix is complete
+      continue;
+    }
+    if (cmd == kCmdFactor) {
+      const bool bad = ldlt_factor_share<SLOTS>(M, N, lane, wave, WAVES, ctrl + 2);
+      if (lane == 0) ctrl[3 + wave] = bad ? 1.0 : 0.0;
+      __syncthreads();                                 // B: factorisation complete
       continue;
     }
     double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
@@ -682,6 +729,25 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     }
   };
 
+  // LDL^T of M in place; with four waves the panels are dealt round-robin (ldlt_factor_share)
+  auto factor = [&]() -> bool {
+    constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
+    if constexpr (WAVES > 1) {
+      volatile lds_f64 *ctrl = ctrl_word(lds, N, nc);
+      if (lane == 0) { ctrl[0] = (double)kCmdFactor; ctrl[2] = 0.0; }
+      __syncthreads();                                 // A
+      const bool mine = ldlt_factor_share<SLOTS>(M, N, lane, 0, WAVES, ctrl + 2);
+      if (lane == 0) ctrl[3] = mine ? 1.0 : 0.0;
+      __syncthreads();                                 // B
+      bool bad = false;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) bad = bad || (ctrl[3 + w] != 0.0);
+      return bad;
+    } else {
+      return ldlt_factor<SLOTS>(M, N, lane);
+    }
+  };
+
   // ---- presolve (fcc_qp.cpp:159-178): skipped on warm start unless equality-only ---------
   if (x0_given) {
     flags |= kFlagPresolveRan | kFlagPresolveNumerical | kFlagPresolveCod;
@@ -689,7 +755,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     flags |= kFlagPresolveRan;
     assemble(0.0);
     const long long t0 = wall_clock64();
-    const bool bad = ldlt_factor<SLOTS>(M, N, lane);
+    const bool bad = factor();
     ticks += wall_clock64() - t0;
     if (bad) {
       flags |= kFlagPresolveNumerical;
@@ -724,7 +790,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   if (!equality_constrained) {
     assemble(a.rho);                                   // :62-64
     const long long t0 = wall_clock64();
-    const bool bad = ldlt_factor<SLOTS>(M, N, lane);   // :68 (info() unchecked in the reference)
+    const bool bad = factor();                         // :68 (info() unchecked in the reference)
     ticks += wall_clock64() - t0;
     if (bad) flags |= kFlagAdmmNumerical;
 
@@ -1046,8 +1112,8 @@ hipError_t launch_widen(const float *src, double *dst, size_t count, hipStream_t
 size_t generic_lds_bytes(int n, int m, int nc) {
   const size_t N = (size_t)n + m;
   // + one panel of slack: the last panel's broadcast reads run up to 15 rows past the matrix
-  // + 2 for the command words of the multi-wave workgroups (ctrl_word)
-  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel + 2);
+  // + the command words of the multi-wave workgroups (ctrl_word)
+  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel + kCtrlWords);
 }
 
 long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {

@@ -1,4 +1,5 @@
-// fccqp_generic.hip -- shape-generic gfx950 kernel: ONE WAVEFRONT (64 lanes) PER QP INSTANCE.
+// fccqp_generic.hip -- shape-generic gfx950 kernel: one wavefront runs one QP instance (plus three
+// helper wavefronts for shapes that own a whole CU's LDS).
 //
 // Hot path replaced (reference /root/reference):
 //   FCCQP::Solve   src/fcc_qp.cpp:114-191   (assemble KKT, presolve, epilogue metrics)
@@ -6,20 +7,23 @@
 //   projections    src/constraint_utils.cpp:5-65
 //   Eigen::LDLT compute/solve at the call sites fcc_qp.cpp:68,86,161,174
 //
-// Design (MI355X): a workgroup is one wavefront, so no barrier is ever needed.  The KKT matrix
-// [[Q(+rho I), A^T],[A, 0]] is assembled once into LDS as a packed lower triangle
-// (column-major, column j holds rows j..N-1 contiguously, so a lane-per-row sweep of a column is
-// bank-conflict free) and factorised in place by an unpivoted LDL^T in natural order (16-column
-// left-looking panels, ldlt_panel below).  The matrix
-// is symmetric quasi-definite for rho > 0 / Q > 0, so every symmetric pivot order exists; the
-// reference's Eigen LDLT pivots by the largest remaining diagonal entry, which only reorders the
-// same block elimination -- results agree to ~1e-13 relative (tests/test_numerics_choice.py).
-// All vectors (rhs, x, duals, bounds) live in registers, lane i owning entries i, i+64, ...
-// Shapes whose packed KKT exceeds the LDS budget (N > 198) keep the matrix in a per-block global
-// workspace and use the unblocked factorisation.
+// Design (MI355X).  The KKT matrix [[Q(+rho I), A^T],[A, 0]] is assembled into LDS as a packed
+// lower triangle (column-major, column j holds rows j..N-1 contiguously, so a lane-per-row sweep
+// of a column is bank-conflict free) and factorised in place by an unpivoted LDL^T in natural
+// order (16-column left-looking panels, ldlt_panel).  The matrix is symmetric quasi-definite for
+// rho > 0 / Q > 0, so every symmetric pivot order exists; the reference's Eigen LDLT pivots by the
+// largest remaining diagonal entry, which only reorders the same block elimination -- results
+// agree to ~1e-13 relative (tests/test_numerics_choice.py).  All vectors (rhs, x, duals, bounds)
+// live in registers, lane i owning entries i, i+64, ... (SLOTS of them).  ADMM iterations start as
+// two triangular sweeps per iteration, like the reference; an instance that keeps iterating
+// switches to the explicit operator x = x_c + (rho G) w (solve_instance).  Shapes with N <= 128
+// run one wave per workgroup and no barrier; shapes with 128 < N <= 198 own a CU's LDS and get
+// four waves, wave 0 the solver and waves 1-3 helpers for assembly, factorisation and the G build
+// (helper_wave).  Shapes whose packed KKT exceeds the LDS budget (N > 198) keep the matrix in a
+// per-block global workspace and use the unblocked factorisation and sweeps only.
 //
 // This is the any-shape path and the first correct HIP path; the shape-specialised kernel in
-// fccqp_fused.hip is the fast one.
+// fccqp_fused.hip is the fast one for the walking shape.
 #include "fccqp_device.h"
 #include "fccqp_cod_impl.h"
 

@@ -78,7 +78,10 @@ def _random_qp(rng, n, m, nc, s, finite_bounds=True):
 
 
 @pytest.mark.parametrize("dims", [(3, 0, 3, 0), (7, 2, 3, 4), (12, 5, 6, 3), (20, 20, 0, 0), (33, 9, 9, 24),
-                                  (64, 0, 12, 10), (65, 63, 3, 0), (100, 40, 30, 50), (130, 70, 24, 100)])
+                                  (64, 0, 12, 10), (65, 63, 3, 0), (100, 40, 30, 50), (130, 70, 24, 100),
+                                  (129, 40, 9, 120),    # 3 slots in LDS, n > 128: four waves, sweeps only
+                                  (120, 76, 12, 100),   # 4 slots in LDS (N = 196): four waves, G batches of 8
+                                  (128, 1, 3, 125)])    # n exactly two slots wide
 def test_odd_shapes_match_oracle(oracle, dims):
     """Ragged sizes around the wavefront width (64) and the register-slot boundaries (128, 192)."""
     n, m, nc, s = dims
@@ -339,3 +342,57 @@ def test_fp32_storage_rank_deficient_presolve(oracle):
     assert d32[4].flags & CAPI.FLAG_PRESOLVE_COD
     z_ref, it_ref, _ = oracle_batch(oracle, P.WALKING.ctor_args, P.HARNESS_OPTIONS, wide)
     assert_parity(z32, [x.n_iter for x in d32], z_ref, it_ref, tol=Z_TOL, what="fp32 storage + cod")
+
+
+# ---- the four-wave workgroups of 3-4 slot shapes (fccqp_generic.hip helper_wave) ------------------
+def test_large_shape_warm_start_chain(oracle):
+    """Warm-started sequence on the large shape: no presolve after the first solve, the helper
+    waves only see factor / build commands, state carried on the device."""
+    chains, steps = 8, 4
+    seqs = [P.gait_sequence(steps, P.LARGE, seed0=9000 + 50 * c) for c in range(chains)]
+    opts = dict(max_iter=40, rho=5e-5, eps_fcone=1e-6, eps_bound=1e-6)     # > 8: the G switch is taken
+    solver = CAPI.Solver(*P.LARGE.ctor_args, batch=chains); solver.set_options(**opts)
+    orcs = []
+    for c in range(chains):
+        o = oracle.OracleFCCQP(*P.LARGE.ctor_args)
+        op = oracle.FCCQPOptions(); op.__dict__.update(opts); o.set_options(op)
+        orcs.append(o)
+    for t in range(steps):
+        B = P.stack([seqs[c][t] for c in range(chains)])
+        solver.set_warm_start(t > 0)
+        solver.solve_ok(*B.arrays())
+        z, d = solver.solution()
+        z_ref = np.zeros_like(z); it_ref = []
+        for c, o in enumerate(orcs):
+            o.set_warm_start(t > 0)
+            o.Solve(**seqs[c][t]); sol = o.GetSolution()
+            z_ref[c] = sol.z; it_ref.append(sol.details.n_iter)
+        assert_parity(z, [x.n_iter for x in d], z_ref, it_ref, tol=Z_TOL, what=f"large chain step {t}")
+
+
+def test_large_shape_rank_deficient_presolve(oracle):
+    """Bad presolve pivot on a four-wave workgroup: wave 0 leaves early (the helpers must be
+    released), and the list-mode fallback launch runs COD + ADMM with the helpers attached."""
+    base = P.workload("W-mix", 6, P.LARGE)
+    qps = [base.instance(i) for i in range(6)]
+    for i, j in {1: 40, 4: 50}.items():
+        qps[i] = _dead_variable(qps[i], j)
+    B = P.stack(qps)
+    z_ref, it_ref, det_ref = oracle_batch(oracle, P.LARGE.ctor_args, P.HARNESS_OPTIONS, B)
+    z, it, d, _ = gpu_solve(P.LARGE, P.HARNESS_OPTIONS, B)
+    assert_parity(z, it, z_ref, it_ref, tol=Z_TOL, what="large cod fallback")
+    for i in range(6):
+        assert bool(d[i].flags & CAPI.FLAG_PRESOLVE_COD) == (i in (1, 4))
+        assert det_ref[i].presolve_ldlt_info == (1 if i in (1, 4) else 0)
+
+
+def test_sweeps_and_operator_iterations_agree(oracle):
+    """max_iter below / at / above the switch from triangular sweeps to x = x_c + (rho G) w give the
+    oracle's iterates either way (walking shape on the generic kernel switches at 16, large at 8)."""
+    for shape, its in ((P.WALKING, (15, 16, 17, 40)), (P.LARGE, (7, 8, 9, 30))):
+        B = P.workload("W-sat", 8, shape)
+        for mi in its:
+            opts = dict(P.HARNESS_OPTIONS); opts["max_iter"] = mi
+            z_ref, it_ref, _ = oracle_batch(oracle, shape.ctor_args, opts, B)
+            z, it, _, _ = gpu_solve(shape, opts, B, CAPI.KERNEL_GENERIC)
+            assert_parity(z, it, z_ref, it_ref, tol=Z_TOL_TIGHT, what=f"{shape.ctor_args} max_iter={mi}")

@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU (metric: 4096)")
     ap.add_argument("--workload", default="W-sat", choices=["W-sat", "W-mix", "W-easy"])
+    ap.add_argument("--shape", default="walking", choices=["walking", "large"],
+                    help="walking = FCCQP(60,38,12,38), the metric's shape; large = FCCQP(114,60,24,66), "
+                         "BASELINE configs[3] (secondary: generic kernel, four waves per QP)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fused"])
     ap.add_argument("--options", default="harness", choices=["harness", "paper"],
                     help="harness: fcc_qp_test.py:78-83 (headline); paper: fccqp.pdf Table 1 (max_iter=15, eps=1e-4)")
@@ -58,6 +61,21 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     return ap.parse_args()
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector fp64 (MI355X_MICROARCH.md)
+
+
+def fp64_diag(shape, warm, n_iter_mean, at_max_frac, nb, kernel_ms):
+    """Algorithmic flops of the reference algorithm per launch: f
+    factorisations of N^3/3, p presolve back-solves and K iterations of 2 N^2 each."""
+    N = shape.n + shape.m
+    f, p = (1, 0) if warm else (2, 1)
+    k_exec = n_iter_mean + (1.0 - at_max_frac)        # a converged instance executed n_iter + 1 iterations
+    flops = nb * (f * N ** 3 / 3.0 + (p + k_exec) * 2.0 * N * N)
+    ach = flops / (kernel_ms * 1e-3) / 1e12
+    return {"flops_per_launch": flops, "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / FP64_VECTOR_PEAK_TFLOPS}
 
 
 def cpu_baseline(shape, options, batch_obj, log):
@@ -139,11 +157,13 @@ def main():
     from fcc_qp_amd import problems as P
     from fcc_qp_amd import sharding as S
 
-    shape = P.WALKING
+    shape = P.WALKING if args.shape == "walking" else P.LARGE
     options = dict(P.HARNESS_OPTIONS if args.options == "harness" else P.PAPER_OPTIONS)
     nb = args.batch
     t0 = time.time()
-    batch = P.workload(args.workload, nb, shape, seed0=S.rank_seed0(rank, nb))   # instance i: seed 1000 + i
+    # instance i: seed 1000 + i (the large shape's generator is slow: 64 distinct instances, tiled)
+    batch = P.workload(args.workload, nb, shape, seed0=S.rank_seed0(rank, nb),
+                       **({"distinct": 64} if args.shape == "large" else {}))
     log(f"[bench] generated {nb} '{args.workload}' instances per rank in {time.time() - t0:.1f} s")
 
     solver = F.FCCQPBatch(*shape.ctor_args, nb, dev_index)
@@ -214,17 +234,19 @@ def main():
         if os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
-                if tr.get("batch") == nb and tr.get("workload") == args.workload and tr.get("kernel") == solver.kernel_in_use():
+                if tr.get("batch") == nb and tr.get("workload") == args.workload and tr.get("kernel") == solver.kernel_in_use() \
+                        and args.shape == "walking" and args.inputs == "f64" and not args.warm:
                     traffic = tr.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "QP solves/sec at batch=4096, walking-log shape",
+            "metric": ("QP solves/sec at batch=4096, walking-log shape" if args.shape == "walking" else
+                       "QP solves/sec, 36-DoF / 8-contact shape (BASELINE configs[3], secondary)"),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: FCCQP(60,38,12,38) walking-shape OSC QPs, "
+                "workload": f"{args.workload}: FCCQP{tuple(shape.ctor_args)} {args.shape}-shape OSC QPs, "
                             f"{'warm' if args.warm else 'cold'} start, rho={options['rho']:g} "
                             f"eps={options['eps_fcone']:g}/{options['eps_bound']:g} max_iter={options['max_iter']} "
                             f"({'fcc_qp_test.py:78-83' if args.options == 'harness' else 'fccqp.pdf Table 1'})",
@@ -236,6 +258,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms_mean": mean_ms, "kernel_ms_min": float(np.min(kernel_ms)),
                          "algorithmic_bytes_per_launch": alg_bytes},
+            # diagnostic beside the contractual HBM roofline: algorithmic flops
+            # F = f N^3/3 + (p + K) 2 N^2 per solve against the 78.6 TFLOP/s vector-fp64 peak
+            "fp64": fp64_diag(shape, args.warm, float(n_iter.mean()), float(np.mean(n_iter == options["max_iter"])),
+                              nb, mean_ms),
             "parity": parity,
         }
         if world == 1 and not args.no_cpu_baseline:

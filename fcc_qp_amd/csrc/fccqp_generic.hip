@@ -574,6 +574,70 @@ __device__ __forceinline__ void assemble_share(MP M, const TIN *Q, const TIN *A,
   }
 }
 
+// ---- the operator iteration's mat-vec: acc += (rho G)[rows of this lane][columns of chunks [cb, ce)] w
+// rho*G sits column-major at M[0 .. n*n), w zero-padded at M[w_off ..) (g_w_off / g_w_len), both in
+// LDS.  A chunk is CH = 3 column pairs.  Left alone the compiler serialises this loop (one load, one
+// wait, one FMA, same register): the operands of a whole chunk are loaded into distinct registers
+// first, and the next chunk's loads are issued before this chunk's FMAs.  Chunks up to ce + 1 are
+// fetched (never applied): w is zero-filled two chunks past the last real one and column indices
+// are clamped.
+constexpr int kMvPairs = 3;
+__device__ __forceinline__ int g_w_off(int n) { return (n * n + 1) & ~1; }
+__device__ __forceinline__ int g_chunks(int n) { return ((n + 1) / 2 + kMvPairs - 1) / kMvPairs; }
+__device__ __forceinline__ int g_w_len(int n) { return 2 * kMvPairs * (g_chunks(n) + 2); }
+__device__ __forceinline__ int g_part_off(int n) { return g_w_off(n) + g_w_len(n); }   // [4][128] partial sums
+
+template <int GS>
+__device__ __forceinline__ void matvec_range(const lds_f64 *M, const int n, const int lane, const int cbeg,
+                                             const int cend, double (&acc0)[GS], double (&acc1)[GS]) {
+  constexpr int CH = kMvPairs;
+  int rc2[GS];
+#pragma unroll
+  for (int t = 0; t < GS; ++t) {
+    const int i = lane + kWave * t;
+    rc2[t] = (i < n) ? i : n - 1;
+  }
+  const lds_d2 *w2 = reinterpret_cast<const lds_d2 *>(M + g_w_off(n));
+  struct Chunk { d2 w[CH]; double ga[CH][GS], gb[CH][GS]; };
+  auto fetch = [&](const int c, Chunk &o) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int jp = c * CH + u;
+      o.w[u] = w2[jp];
+      const int j0 = (2 * jp < n) ? 2 * jp : n - 1, j1 = (2 * jp + 1 < n) ? 2 * jp + 1 : n - 1;
+#pragma unroll
+      for (int t = 0; t < GS; ++t) {
+        o.ga[u][t] = M[j0 * n + rc2[t]];
+        o.gb[u][t] = M[j1 * n + rc2[t]];
+      }
+    }
+  };
+  auto apply = [&](const Chunk &o) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+#pragma unroll
+      for (int t = 0; t < GS; ++t) {
+        acc0[t] = fma(o.ga[u][t], o.w[u].x, acc0[t]);
+        acc1[t] = fma(o.gb[u][t], o.w[u].y, acc1[t]);
+      }
+    }
+  };
+  if (cbeg >= cend) return;
+  Chunk ca, cb;
+  fetch(cbeg, ca);
+#pragma nounroll
+  for (int c = cbeg; c < cend; c += 2) {
+    fetch(c + 1, cb);
+    __builtin_amdgcn_sched_barrier(0);
+    apply(ca);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(c + 2, ca);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < cend) apply(cb);                     // the range may hold an odd number of chunks
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // ---- building rho*G with several waves ----------------------------------------------------------
 // Shapes that need three or four register slots own a whole CU's LDS (one workgroup per CU), so
 // their workgroup is launched with four waves, one per SIMD: wave 0 runs the solver, waves 1-3
@@ -584,7 +648,7 @@ template <int SLOTS, bool MAT_IN_LDS>
 constexpr int waves_for() { return (MAT_IN_LDS && SLOTS >= 3 && SLOTS <= 4) ? 4 : 1; }
 template <int SLOTS>
 constexpr int g_batch() { return (SLOTS <= 3) ? 16 : 8; }   // right-hand sides per substitution batch
-constexpr int kCmdBuild = 1, kCmdDone = 2, kCmdAssemble = 3, kCmdFactor = 4;
+constexpr int kCmdBuild = 1, kCmdDone = 2, kCmdAssemble = 3, kCmdFactor = 4, kCmdMatvec = 5;
 // command words (doubles after the panel slack): [0] command, [1] rho, [2] finished-panel count of a
 // shared factorisation, [3 + wave] that wave's bad-pivot flag
 constexpr int kCtrlWords = 8;
@@ -641,6 +705,18 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       const TIN *A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * a.m * n;
       assemble_share<TIN>(M, Q, A, n, N, (double)ctrl[1], lane, wave, WAVES);
       __syncthreads();                                 // B: the matrix is complete
+      continue;
+    }
+    if (cmd == kCmdMatvec) {                           // this wave's quarter of x = x_c + (rho G) w
+      constexpr int GS = 2;
+      double acc0[GS] = {0.0, 0.0}, acc1[GS] = {0.0, 0.0};
+      const int nchunk = g_chunks(n), per = (nchunk + WAVES - 1) / WAVES;
+      const int cb = wave * per, ce = ((wave + 1) * per < nchunk) ? (wave + 1) * per : nchunk;
+      matvec_range<GS>(M, n, lane, cb, ce, acc0, acc1);
+      lds_f64 *part = M + g_part_off(n);
+#pragma unroll
+      for (int t = 0; t < GS; ++t) part[wave * 2 * kWave + lane + kWave * t] = acc0[t] + acc1[t];
+      __syncthreads();                                 // B
       continue;
     }
     if (cmd == kCmdFactor) {
@@ -825,13 +901,14 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     constexpr int RB = g_batch<SLOTS>();
     constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
     const int gswitch = (WAVES > 1) ? kGSwitchIterMulti : kGSwitchIter;
-    const int g_off = 0, w_off = (n * n + 1) & ~1;     // LDS doubles: rho*G [n][n] (column-major), w [w_len]
-    const int w_len = 6 * (((n + 1) / 2 + 2) / 3 + 2); // w zero-padded for the chunked mat-vec (3 pairs per chunk)
+    // LDS doubles after the switch: rho*G [n][n] (column-major) | w [w_len], zero-padded | partial sums
+    const int g_off = 0, w_off = g_w_off(n), w_len = g_w_len(n);
     bool use_g = false, g_ready = false;
     if constexpr (MAT_IN_LDS && SLOTS <= 4) {
       use_g = a.workspace != nullptr && n <= 2 * kWave && n > 0 && w_off + w_len <= npack &&
               a.workspace_stride >= (long long)n * n;
     }
+    const bool coop_mv = (WAVES > 1) && g_part_off(n) + WAVES * 2 * kWave <= npack;
     double xc[GS];
 #pragma unroll
     for (int t = 0; t < GS; ++t) xc[t] = 0.0;
@@ -864,62 +941,38 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
       if (g_ready) {
         if constexpr (MAT_IN_LDS && SLOTS <= 4) {
           lds_f64 *wbuf = M + w_off;
-          int rc2[GS];
 #pragma unroll
           for (int t = 0; t < GS; ++t) {
             const int i = lane + kWave * t;
-            rc2[t] = (i < n) ? i : n - 1;
             if (i < n) wbuf[i] = is_cone[t] ? (lcbar[t] - mulc[t]) : (xbar[t] - mux[t]);
           }
-          // zero pad up to a whole number of chunks (g_ok checked the room): padded pairs multiply a
-          // clamped, valid column of G by w = 0
-          constexpr int CH = 3;                        // column pairs per chunk: 3 + 12 loads <= 15 (lgkmcnt)
-          const int npair = (n + 1) / 2, nchunk = (npair + CH - 1) / CH;
-          for (int i = n + lane; i < 2 * CH * (nchunk + 2); i += kWave) wbuf[i] = 0.0;   // == w_len
-          wave_sync();
+          // zero pad (use_g checked the room): padded pairs multiply a clamped, valid column by w = 0
+          const int nchunk = g_chunks(n);
+          for (int i = n + lane; i < w_len; i += kWave) wbuf[i] = 0.0;
           double acc0[GS], acc1[GS];
 #pragma unroll
           for (int t = 0; t < GS; ++t) { acc0[t] = xc[t]; acc1[t] = 0.0; }
-          const lds_d2 *w2 = reinterpret_cast<const lds_d2 *>(wbuf);
-          // Left alone the compiler serialises this loop (one load, one wait, one FMA, same
-          // register); the operands of a whole chunk are loaded into distinct registers first, and
-          // the next chunk's loads are issued before this chunk's FMAs.
-          struct Chunk { d2 w[CH]; double ga[CH][GS], gb[CH][GS]; };
-          auto fetch = [&](const int c, Chunk &o) {
+          if constexpr (WAVES > 1) {
+            if (coop_mv) {
+              // the four waves take a quarter of the columns each; partial sums meet in LDS
+              const int per = (nchunk + WAVES - 1) / WAVES;
+              if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdMatvec;
+              __syncthreads();                         // A: w is in LDS
+              matvec_range<GS>(M, n, lane, 0, (per < nchunk) ? per : nchunk, acc0, acc1);
+              __syncthreads();                         // B: the helpers' partial sums are in LDS
+              const lds_f64 *part = M + g_part_off(n);
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-              const int jp = c * CH + u;
-              o.w[u] = w2[jp];
-              const int j0 = (2 * jp < n) ? 2 * jp : n - 1, j1 = (2 * jp + 1 < n) ? 2 * jp + 1 : n - 1;
+              for (int w = 1; w < WAVES; ++w) {
 #pragma unroll
-              for (int t = 0; t < GS; ++t) {
-                o.ga[u][t] = M[g_off + j0 * n + rc2[t]];
-                o.gb[u][t] = M[g_off + j1 * n + rc2[t]];
+                for (int t = 0; t < GS; ++t) acc0[t] += part[w * 2 * kWave + lane + kWave * t];
               }
+            } else {
+              wave_sync();
+              matvec_range<GS>(M, n, lane, 0, nchunk, acc0, acc1);
             }
-          };
-          auto apply = [&](const Chunk &o) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-#pragma unroll
-              for (int t = 0; t < GS; ++t) {
-                acc0[t] = fma(o.ga[u][t], o.w[u].x, acc0[t]);
-                acc1[t] = fma(o.gb[u][t], o.w[u].y, acc1[t]);
-              }
-            }
-          };
-          Chunk ca, cb;
-          fetch(0, ca);
-#pragma nounroll
-          for (int c = 0; c < nchunk; c += 2) {
-            fetch(c + 1, cb);                          // c + 1 <= nchunk: at worst an all-padding chunk
-            __builtin_amdgcn_sched_barrier(0);
-            apply(ca);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(c + 2, ca);                          // may also be padding (w zero-filled to nchunk + 1)
-            __builtin_amdgcn_sched_barrier(0);
-            apply(cb);
-            __builtin_amdgcn_sched_barrier(0);
+          } else {
+            wave_sync();
+            matvec_range<GS>(M, n, lane, 0, nchunk, acc0, acc1);
           }
 #pragma unroll
           for (int t = 0; t < SLOTS; ++t) x[t] = 0.0;

@@ -403,11 +403,10 @@ int fccqp_solve_device_f32(fccqp_solver *s, const float *dQ, const float *db, co
   int rc = ensure_vec_staging(s);
   if (rc != FCCQP_OK) return rc;
   hipStream_t st = (stream == FCCQP_STREAM_OWN) ? s->stream : reinterpret_cast<hipStream_t>(stream);
-  HIP_TRY(s, fccqp::launch_widen(db, s->wb, B * n, st));
-  HIP_TRY(s, fccqp::launch_widen(db_eq, s->wbeq, B * m, st));
-  HIP_TRY(s, fccqp::launch_widen(dfriction, s->wmu, B * nm, st));
-  HIP_TRY(s, fccqp::launch_widen(dlb, s->wlb, B * n, st));
-  HIP_TRY(s, fccqp::launch_widen(dub, s->wub, B * n, st));
+  const float *const src[5] = {db, db_eq, dfriction, dlb, dub};
+  double *const dst[5] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub};
+  const size_t cnt[5] = {B * n, B * m, B * nm, B * n, B * n};
+  HIP_TRY(s, fccqp::launch_widen5(src, dst, cnt, st));
   s->last_solve_wall = 0.0;
   return enqueue(s, reinterpret_cast<const double *>(dQ), s->wb, reinterpret_cast<const double *>(dA_eq),
                  s->wbeq, s->wmu, s->wlb, s->wub, st, /*qa_f32=*/true);

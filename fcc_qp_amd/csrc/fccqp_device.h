@@ -63,8 +63,10 @@ hipError_t launch_generic(const KernelArgs &a, size_t lds_limit, hipStream_t str
 hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream,
                                bool qa_f32);
 
-// widens count floats to doubles (small per-instance vectors of the fp32-storage entry points)
-hipError_t launch_widen(const float *src, double *dst, size_t count, hipStream_t stream);
+// widens five float arrays to double in one launch (the small per-instance vectors of the
+// fp32-storage entry points)
+hipError_t launch_widen5(const float *const src[5], double *const dst[5], const size_t count[5],
+                         hipStream_t stream);
 
 // ---- presolve fallback workspace (fccqp_cod_impl.h) ---------------------------------------------
 long long cod_workspace_doubles_host(int n, int m);

@@ -1151,18 +1151,30 @@ hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, 
   return hipGetLastError();
 }
 
-__global__ void widen_kernel(const float *__restrict__ src, double *__restrict__ dst, size_t count) {
+// the five small per-instance vectors of an fp32-storage solve, float -> double, in one launch
+struct WidenJob { const float *src[5]; double *dst[5]; size_t count[5]; };
+__global__ void widen_kernel(const WidenJob job) {
+  const float *src = job.src[blockIdx.y];
+  double *dst = job.dst[blockIdx.y];
+  const size_t count = job.count[blockIdx.y];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = (double)src[i];
 }
 
 }  // namespace
 
-hipError_t launch_widen(const float *src, double *dst, size_t count, hipStream_t stream) {
-  if (count == 0) return hipSuccess;
-  const size_t want = (count + 255) / 256;
-  const int blocks = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(widen_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, count);
+hipError_t launch_widen5(const float *const src[5], double *const dst[5], const size_t count[5],
+                         hipStream_t stream) {
+  WidenJob job;
+  size_t most = 0;
+  for (int k = 0; k < 5; ++k) {
+    job.src[k] = src[k]; job.dst[k] = dst[k]; job.count[k] = count[k];
+    most = count[k] > most ? count[k] : most;
+  }
+  if (most == 0) return hipSuccess;
+  const size_t want = (most + 255) / 256;
+  const int blocks = (int)(want < 1024 ? want : 1024);
+  hipLaunchKernelGGL(widen_kernel, dim3(blocks, 5), dim3(256), 0, stream, job);
   return hipGetLastError();
 }
 

@@ -396,3 +396,44 @@ def test_sweeps_and_operator_iterations_agree(oracle):
             z_ref, it_ref, _ = oracle_batch(oracle, shape.ctor_args, opts, B)
             z, it, _, _ = gpu_solve(shape, opts, B, CAPI.KERNEL_GENERIC)
             assert_parity(z, it, z_ref, it_ref, tol=Z_TOL_TIGHT, what=f"{shape.ctor_args} max_iter={mi}")
+
+
+# ---- edge values of the domain ---------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_edge_values_match_oracle(oracle, kernel):
+    """mu = 0 (cone degenerates to the +z axis), lb == ub (a pinned variable), all-infinite bounds
+    with contacts, huge friction, a bound that cuts the unconstrained optimum, lb > ub (the clamp is
+    min-then-max: constraint_utils.cpp:43), and scaled copies of a problem (1e-3 ... 1e3)."""
+    base = P.workload("W-mix", 12, P.WALKING)
+    qps = [base.instance(i) for i in range(12)]
+    qps[0]["friction_coeffs"] = np.zeros(4)
+    qps[1]["lb"][22:32] = 5.0; qps[1]["ub"][22:32] = 5.0
+    qps[2]["lb"][:] = -np.inf; qps[2]["ub"][:] = np.inf
+    qps[3]["friction_coeffs"] = np.full(4, 1e3)
+    qps[4]["lb"][22:32] = -1.0; qps[4]["ub"][22:32] = 1.0
+    qps[5]["lb"][22] = 3.0; qps[5]["ub"][22] = -3.0
+    for i, sc in ((6, 1e-3), (7, 1e3)):     # cost scaled: same minimiser, different conditioning vs rho
+        qps[i]["Q"] = qps[i]["Q"] * sc; qps[i]["b"] = qps[i]["b"] * sc
+    qps[8]["friction_coeffs"] = np.array([0.0, 0.6, 1e3, 0.05])
+    B = P.stack(qps)
+    for opts in (P.HARNESS_OPTIONS, dict(max_iter=300, rho=1e-2, eps_fcone=1e-8, eps_bound=1e-8)):
+        z_ref, it_ref, _ = oracle_batch(oracle, P.WALKING.ctor_args, opts, B)
+        z, it, d, _ = gpu_solve(P.WALKING, opts, B, kernel)
+        assert np.all(np.isfinite(z))
+        assert_parity(z, it, z_ref, it_ref, tol=Z_TOL, what=f"edge values k{kernel} {opts['max_iter']}")
+
+
+def test_fused_and_generic_kernels_agree_on_a_random_population():
+    """Two independent device implementations (panel LDL^T + G mat-vec from iteration 0 / sweeps then
+    G) on 512 instances drawn across the whole activity range."""
+    rng = np.random.default_rng(77)
+    qps = [P.osc_qp(30000 + i, P.WALKING, activity=float(rng.uniform(0.0, 6.0))) for i in range(128)]
+    B = P.stack(qps * 4)
+    zs = []
+    for kernel in (CAPI.KERNEL_FUSED, CAPI.KERNEL_GENERIC):
+        z, it, d, _ = gpu_solve(P.WALKING, P.HARNESS_OPTIONS, B, kernel)
+        zs.append((z, it))
+    err = rel_err(zs[0][0], zs[1][0])
+    assert err.max() <= Z_TOL_TIGHT, err.max()
+    assert np.max(np.abs(zs[0][1] - zs[1][1])) <= 1
+    assert np.array_equal(zs[0][0][:128], zs[0][0][128:256])     # tiled copies: bit-identical

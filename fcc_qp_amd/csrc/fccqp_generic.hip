@@ -125,6 +125,9 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
 constexpr int kPanel = 16;
 constexpr int kGSwitchIter = 16;       // ADMM iterations by triangular sweeps before G is built ...
 constexpr int kGSwitchIterMulti = 8;   // ... when four waves share the build (it is ~3x cheaper)
+// G is only built if at least this many iterations can still follow (the build costs about that
+// many sweep iterations: it cannot pay off under a small max_iter, e.g. the paper's 15)
+constexpr int kGMinRemaining = 32, kGMinRemainingMulti = 16;
 using d2 = double __attribute__((ext_vector_type(2)));
 using lds_d2 = __attribute__((address_space(3))) d2;
 
@@ -906,7 +909,8 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     bool use_g = false, g_ready = false;
     if constexpr (MAT_IN_LDS && SLOTS <= 4) {
       use_g = a.workspace != nullptr && n <= 2 * kWave && n > 0 && w_off + w_len <= npack &&
-              a.workspace_stride >= (long long)n * n;
+              a.workspace_stride >= (long long)n * n &&
+              a.max_iter - gswitch >= ((WAVES > 1) ? kGMinRemainingMulti : kGMinRemaining);
     }
     const bool coop_mv = (WAVES > 1) && g_part_off(n) + WAVES * 2 * kWave <= npack;
     double xc[GS];

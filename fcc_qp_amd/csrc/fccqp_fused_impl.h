@@ -183,6 +183,61 @@ struct Shape {
 template <class SH>
 struct P3;
 
+// Bulk update of a panel on the matrix cores.  For the 16 columns c0..c0+15 and every row >= c0,
+//   K[i][j] -= sum_{q < c0} (L[i][q] d_q) L[j][q]
+// is a (rows x c0) by (c0 x 16) product.  v_mfma_f64_16x16x4_f64 has the same peak as the fp64
+// VALU, so this is not about flops: on the VALU the update runs lane = row with the L[j][q]
+// operands broadcast out of LDS (one 1-KiB ds_read_b128 return per two FMAs, and 20-60 % of the
+// lanes idle in the triangular panels), while the MFMA takes its operands one element per lane
+// (A[i][k] = lane i + 16 k, B[k][n] = lane n + 16 k: one ds_read_b64 each, no broadcast) and only
+// the row blocks at or below the panel are touched.  The tiles are read from and written back to
+// the panel's own columns in LDS, so the rest of factor_panel (load, in-panel step, write-back)
+// is unchanged.  Layouts (cdna_hip_programming.md): C/D col = lane & 15, row = (lane >> 4) + 4 r.
+using d4 = double __attribute__((ext_vector_type(4)));
+template <class SH>
+__device__ __forceinline__ void mfma_bulk(lds_f64 *M, const lds_f64 *dvec, const int lane, const int c0) {
+  constexpr int N = SH::N, NRB = (N + 15) / 16;
+  const int col = lane & 15, grp = lane >> 4;
+  const int rb0 = c0 >> 4;                               // first row block that holds rows >= c0
+  const int j = (c0 + col < N) ? c0 + col : N - 1;       // this lane's panel column (clamped)
+  const int cbj = SH::cbase(j);
+  d4 acc[NRB];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    if (rb >= rb0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[rb][r] = M[cbj + 16 * rb + grp + 4 * r];   // rows past N-1: garbage rows
+    }
+  }
+#pragma nounroll
+  for (int q0 = 0; q0 < c0; q0 += 4) {
+    const int cq = SH::cbase(q0 + grp);                  // column q0 + k of this lane's k = grp
+    const double b = M[cq + c0 + col];                   // B[k][n] = L[c0 + n][q0 + k]
+    const double nd = -dvec[q0 + grp];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+      if (rb >= rb0) {
+        const double av = M[cq + 16 * rb + col] * nd;    // A[i][k] = -L[16 rb + i][q0 + k] d_{q0 + k}
+        acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc[rb], 0, 0, 0);
+      }
+    }
+  }
+  lds_fence();
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    if (rb >= rb0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rb + grp + 4 * r;
+        // on or below the diagonal of an existing column only: above it the address belongs to the
+        // previous column's tail
+        if (row < N && c0 + col < N && row >= c0 + col) M[cbj + row] = acc[rb][r];
+      }
+    }
+  }
+  lds_fence();
+}
+
 // Left-looking panel LDL^T, in place in LDS.  On return M holds L below the diagonal, the
 // diagonal slots hold 1/d (0 where |d| <= DBL_MIN: Eigen's LDLT::solve rule) and dvec holds d.
 // Returns true if a pivot was zero or not finite (where Eigen's info() can fail).
@@ -198,6 +253,8 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
   const int row0 = lane, row1 = kWave + lane;
   const int r0c = (row0 < N) ? row0 : N - 1;   // clamped rows: in-bounds reads for idle lanes
   const int r1c = (row1 < N) ? row1 : N - 1;
+  // (b) first: the contribution of every earlier column, on the matrix cores, in place in LDS
+  if (c0 > 0) mfma_bulk<SH>(M, dvec, lane, c0);
   double T0[P], T1[P];
   // (a) panel columns into registers
 #pragma unroll
@@ -206,48 +263,6 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
     const int cb = SH::cbase(j);
     T0[jj] = USE0 ? M[cb + r0c] : 0.0;
     T1[jj] = M[cb + r1c];
-  }
-  // (b) contribution of every earlier column q:  T[i][j] -= (L[i][q] d_q) L[j][q]
-  // two columns per trip, operands of the next column loaded before the FMAs of the current one
-  // (c0 is a multiple of 16, so q and q+1 are always both < c0)
-  struct Ops { d2 w[P / 2]; double u0, u1, dq; };
-  auto fetch = [&](const int cb, const int q, Ops &o) {
-    const lds_d2 *bc = reinterpret_cast<const lds_d2 *>(M + cb + c0);  // rows c0.. of column q
-#pragma unroll
-    for (int t = 0; t < P / 2; ++t) o.w[t] = bc[t];  // may run past row N-1 in the last panel: unused
-    o.dq = dvec[q];
-    o.u0 = USE0 ? M[cb + r0c] : 0.0;
-    o.u1 = M[cb + r1c];
-  };
-  auto apply = [&](const Ops &o) {
-    const double u1 = o.u1 * o.dq;
-    if constexpr (USE0) {
-      const double u0 = o.u0 * o.dq;
-#pragma unroll
-      for (int t = 0; t < P / 2; ++t) {
-        T0[2 * t] = fma(-u0, o.w[t].x, T0[2 * t]);
-        T0[2 * t + 1] = fma(-u0, o.w[t].y, T0[2 * t + 1]);
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < P / 2; ++t) {
-      T1[2 * t] = fma(-u1, o.w[t].x, T1[2 * t]);
-      T1[2 * t + 1] = fma(-u1, o.w[t].y, T1[2 * t + 1]);
-    }
-  };
-  if (c0 > 0) {
-    Ops oa, ob;
-    int cb = SH::cbase(0);
-    fetch(cb, 0, oa);
-#pragma nounroll
-    for (int q = 0; q < c0; q += 2) {
-      cb += SH::cstep(q);
-      fetch(cb, q + 1, ob);
-      apply(oa);
-      cb += SH::cstep(q + 1);
-      fetch(cb, (q + 2 < N) ? q + 2 : q + 1, oa);   // one column past the end on the last trip: unused
-      apply(ob);
-    }
   }
   // (c) factorise the panel itself, column by column.  All 16 panel rows live in one register
   // slot (64 is a multiple of 16), so the multipliers l_{c0+jj, j} of the in-panel update are
@@ -623,11 +638,18 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     double xbar = x, lcbar = x;  // :74-75
     double xr = 0.0, lr = 0.0;
     n_iter = a.max_iter;         // :78
+    // The loop's wave-uniform operands (lane masks, the two eps) are re-made here as per-lane
+    // VGPR values: as SGPRs their live ranges span P3, the allocator spills them to VGPR lanes and
+    // the loop reloads each one with v_readlane pairs + wait states, several times per iteration;
+    // a VGPR copy costs one v_cmp per use at most (and is parked in an AGPR across P3 for free).
+    int var_i = isvar ? 1 : 0, cone_i = is_cone ? 1 : 0, z_i = (ccomp == 2) ? 1 : 0;
+    double eps_b = a.eps_bound, eps_f = a.eps_fcone;
+    asm volatile("" : "+v"(var_i), "+v"(cone_i), "+v"(z_i), "+v"(eps_b), "+v"(eps_f));
 #pragma nounroll
     for (int iter = 0; iter < a.max_iter; ++iter) {
       // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
-      const double w = is_cone ? (lcbar - mulc) : (xbar - mux);
-      vbuf[lane] = isvar ? w : 0.0;
+      const double w = (cone_i != 0) ? (lcbar - mulc) : (xbar - mux);
+      vbuf[lane] = (var_i != 0) ? w : 0.0;
       lds_fence();
       // x = x_c + (rho G) w   == the KKT solve of :83-87.  w comes back from LDS as broadcast pairs,
       // in chunks of 7 pairs with two chunks in flight (<= 15 loads: the lgkmcnt counter has 4 bits): a lone wave per SIMD has nobody to hide
@@ -671,19 +693,19 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       x = (acc0 + acc1) + (acc2 + acc3);
       lds_fence();
       // slack update :90-92
-      if (is_cone) vbuf[lane] = x + mulc;
+      if (cone_i != 0) vbuf[lane] = x + mulc;
       lds_fence();
       xr = 0.0; lr = 0.0;
-      if (isvar) {
+      if (var_i != 0) {
         const double v = x + mux;
         const double tt = min2(v, vub);   // std::min(x(i), ub(i))   constraint_utils.cpp:43
         xbar = max2(tt, vlb);             // std::max(., lb(i))
         xr = x - xbar;                    // :95
         mux += xr;                        // :101
       }
-      if (is_cone) {
+      if (cone_i != 0) {
         const int base = s0 + 3 * cidx;
-        lcbar = project_cone_component(vbuf[base], vbuf[base + 1], vbuf[base + 2], vmu, x + mulc, ccomp == 2);
+        lcbar = project_cone_component(vbuf[base], vbuf[base + 1], vbuf[base + 2], vmu, x + mulc, z_i != 0);
         lr = x - lcbar;                   // :96
         mulc += lr;                       // :102
       }
@@ -691,9 +713,9 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test
       // is one ballot instead of two wave reductions; the norms themselves (:97-98) are only
       // reported, and are reduced once after the loop.  An empty contact set has norm 0.
-      bool ok = !isvar || (fabs(xr) < a.eps_bound);
-      if constexpr (nc > 0) ok = ok && (!is_cone || (fabs(lr) < a.eps_fcone));
-      else ok = ok && (0.0 < a.eps_fcone);
+      bool ok = (var_i == 0) || (fabs(xr) < eps_b);
+      if constexpr (nc > 0) ok = ok && ((cone_i == 0) || (fabs(lr) < eps_f));
+      else ok = ok && (0.0 < eps_f);
       if (__all(ok)) {
         n_iter = iter;
         break;

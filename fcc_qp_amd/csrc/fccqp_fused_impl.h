@@ -209,17 +209,31 @@ __device__ __forceinline__ void mfma_bulk(lds_f64 *M, const lds_f64 *dvec, const
       for (int r = 0; r < 4; ++r) acc[rb][r] = M[cbj + 16 * rb + grp + 4 * r];   // rows past N-1: garbage rows
     }
   }
-#pragma nounroll
-  for (int q0 = 0; q0 < c0; q0 += 4) {
-    const int cq = SH::cbase(q0 + grp);                  // column q0 + k of this lane's k = grp
-    const double b = M[cq + c0 + col];                   // B[k][n] = L[c0 + n][q0 + k]
-    const double nd = -dvec[q0 + grp];
+  // four columns q0..q0+3 per step (k = grp picks this lane's column); the operands of the next
+  // step are fetched before the MFMAs of the current one (c0 is a multiple of 16: steps pair up)
+  struct Ops { double b, nd, av[NRB]; };
+  auto fetch = [&](const int q0, Ops &o) {
+    const int cq = SH::cbase(q0 + grp);
+    o.b = M[cq + c0 + col];                              // B[k][n] = L[c0 + n][q0 + k]
+    o.nd = -dvec[q0 + grp];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
-      if (rb >= rb0) {
-        const double av = M[cq + 16 * rb + col] * nd;    // A[i][k] = -L[16 rb + i][q0 + k] d_{q0 + k}
-        acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b, acc[rb], 0, 0, 0);
-      }
+    for (int rb = 0; rb < NRB; ++rb)
+      if (rb >= rb0) o.av[rb] = M[cq + 16 * rb + col];   // A[i][k] = L[16 rb + i][q0 + k]  (x -d_q below)
+  };
+  auto apply = [&](const Ops &o) {
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+      if (rb >= rb0) acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[rb] * o.nd, o.b, acc[rb], 0, 0, 0);
+  };
+  {
+    Ops oa, ob;
+    fetch(0, oa);
+#pragma nounroll
+    for (int q0 = 0; q0 < c0; q0 += 8) {
+      fetch(q0 + 4, ob);
+      apply(oa);
+      fetch((q0 + 8 < c0) ? q0 + 8 : q0 + 4, oa);        // last trip: a harmless re-read
+      apply(ob);
     }
   }
   lds_fence();

@@ -252,6 +252,208 @@ __device__ __forceinline__ void mfma_bulk(lds_f64 *M, const lds_f64 *dvec, const
   lds_fence();
 }
 
+// ---- P3 on the matrix cores ------------------------------------------------------------------------
+// X := (L D L^T)^-1 X for the N x 64 block X = [e_0 .. e_{n-1} | -b; b_eq | 0 ..]: a triangular
+// solve with 64 right-hand sides, i.e. a real contraction.  X lives in MFMA accumulator tiles
+// (row block I of 16 rows x column block cb of 16 right-hand sides: 4 doubles per lane, C/D layout
+// col = lane & 15, row = (lane >> 4) + 4 r).  Forward sweep by row blocks:
+//   X_I -= L_IK X_K  (K < I)     v_mfma_f64_16x16x4: A[i][k] = L[16I+i][16K+4r+k] is one ds_read_b64
+//                                per lane (no broadcast), and B[k][n] = X_K[4r+k][n] IS accumulator
+//                                register r of tile X_K -- no data movement at all;
+//   X_I  = L_II^-1 X_I           with the 16x16 diagonal blocks inverted in place beforehand.
+// Then D^-1 (the diagonal slots hold 1/d), the mirrored backward sweep with L^T, and rho*G / x_c go
+// through LDS (over L, which is dead by then) to the lane = row layout the ADMM loop wants.
+// Against the lane-per-right-hand-side VALU version this replaces ~9.6 k FMA + 4.8 k broadcast
+// ds_read_b128 instructions by ~0.8 k MFMA + ~0.3 k ds_read_b64, and 19 k lines of generated code.
+template <class SH>
+__device__ __forceinline__ void invert_diag_blocks(lds_f64 *M, const int lane) {
+  constexpr int N = SH::N, NRB = (N + 15) / 16;
+  // pair p = 16 * block + column: lane handles pairs lane, 64 + lane; y = column j of L_II^-1
+#pragma unroll
+  for (int round = 0; round * kWave < 16 * NRB; ++round) {
+    const int p = round * kWave + lane;
+    const int blk = p >> 4, j = p & 15, r0 = 16 * blk;
+    const bool live = p < 16 * NRB;
+    double y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) y[i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+#pragma unroll
+      for (int k = 0; k < i; ++k) {
+        const bool ok = live && (r0 + i < N);                       // column r0 + k < row r0 + i < N
+        const double l = ok ? M[SH::cbase(ok ? r0 + k : 0) + (ok ? r0 + i : 0)] : 0.0;
+        y[i] = fma(-l, y[k], y[i]);
+      }
+    }
+    lds_fence();   // every lane has read its block before any lane overwrites one
+#pragma unroll
+    for (int i = 1; i < 16; ++i)
+      if (live && i > j && r0 + i < N) M[SH::cbase(r0 + j) + r0 + i] = y[i];
+    lds_fence();
+  }
+}
+
+template <class SH>
+__device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho,
+                                        double (&Mrow)[SH::n], double &xc) {
+  constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NCB = kWave / 16;
+  static_assert(n < kWave, "n + 1 right-hand sides in 64 columns");
+  const int col = lane & 15, grp = lane >> 4;
+  invert_diag_blocks<SH>(M, lane);
+  // right-hand sides: column c < n is e_c, column n is [-b; b_eq] (staged in vbuf), the rest zero
+  d4 X[NRB][NCB];
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + grp + 4 * r;
+      const double rhs = (row < N) ? vbuf[row < N ? row : 0] : 0.0;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int c = 16 * cb + col;
+        X[I][cb][r] = (c < n) ? ((row == c) ? 1.0 : 0.0) : ((c == n) ? rhs : 0.0);
+      }
+    }
+  }
+  lds_fence();
+  // A operands.  Forward: A[i][k] = L[16I + i][4t + k], t = 4K + r: per-lane column base
+  // fwd[t] = &M[cbase(4t + grp) + col], row block = immediate offset 16I.  Backward: A[i][k] =
+  // L[4t + k][16I + i]: bwd[I] = &M[cbase(16I + col) + grp], offset 4t.  Entries outside the
+  // matrix (rows / columns >= N: last row block, k-step t = N/4) and outside the strict triangle
+  // of a diagonal block are zeroed by a select after an in-bounds load; which tiles need that is
+  // known at compile time.  All operands of a row block are fetched before its MFMAs.
+  constexpr int NT = 4 * NRB;
+  const lds_f64 *fwd[NT], *bwd[NRB];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) fwd[t] = M + SH::cbase((4 * t + grp < N) ? 4 * t + grp : N - 1) + col;
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) bwd[I] = M + SH::cbase((16 * I + col < N) ? 16 * I + col : N - 1) + grp;
+  constexpr int kRowEdge = N - 16 * (NRB - 1);   // valid rows in the last row block
+  // ---- forward ------------------------------------------------------------------------------------
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+    double aop[4 * NRB];
+#pragma unroll
+    for (int t = 0; t < 4 * I + 4; ++t) {
+      if (4 * t < N) {
+        double v = fwd[t][16 * I];                                   // rows past N-1 land in allocated LDS
+        bool keep = true;
+        if (I == NRB - 1 && kRowEdge < 16) keep = keep && (col < kRowEdge);
+        if (4 * t + 3 >= N) keep = keep && (4 * t + grp < N);
+        if (t >= 4 * I) keep = keep && (col > 4 * (t - 4 * I) + grp);   // inverted diagonal block: strict lower
+        aop[t] = keep ? ((t >= 4 * I) ? v : -v) : 0.0;
+      } else {
+        aop[t] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4 * I; ++t) {
+      if (4 * t < N) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[t], X[t / 4][cb][t % 4], X[I][cb], 0, 0, 0);
+      }
+    }
+    // X_I = L_II^-1 X_I = X_I + (strictly lower part of the inverted block) X_I
+    d4 T[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) T[cb] = X[I][cb];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (4 * (4 * I + r) < N) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          T[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[4 * I + r], X[I][cb][r], T[cb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) X[I][cb] = T[cb];
+  }
+  // ---- D^-1 (diagonal slots hold 1/d with the pseudo-inverse rule folded in) --------------------------
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + grp + 4 * r;
+      const double rd = (row < N) ? M[SH::cbase(row < N ? row : 0) + (row < N ? row : 0)] : 0.0;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) X[I][cb][r] *= rd;
+    }
+  }
+  // ---- backward: X_I -= L_KI^T X_K (K > I), then X_I = L_II^-T X_I ---------------------------------------
+#pragma unroll
+  for (int I = NRB - 1; I >= 0; --I) {
+    double aop[4 * NRB];
+#pragma unroll
+    for (int t = 4 * I; t < NT; ++t) {
+      if (4 * t < N) {
+        double v = bwd[I][4 * t];                                     // L[4t + grp][16I + col]
+        bool keep = true;
+        if (I == NRB - 1 && kRowEdge < 16) keep = keep && (col < kRowEdge);   // column 16I + col < N
+        if (4 * t + 3 >= N) keep = keep && (4 * t + grp < N);
+        if (t < 4 * I + 4) keep = keep && (4 * (t - 4 * I) + grp > col);      // inverted diagonal block, transposed
+        aop[t] = keep ? ((t < 4 * I + 4) ? v : -v) : 0.0;
+      } else {
+        aop[t] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int t = 4 * I + 4; t < NT; ++t) {
+      if (4 * t < N) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[t], X[t / 4][cb][t % 4], X[I][cb], 0, 0, 0);
+      }
+    }
+    d4 T[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) T[cb] = X[I][cb];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (4 * (4 * I + r) < N) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          T[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[4 * I + r], X[I][cb][r], T[cb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) X[I][cb] = T[cb];
+  }
+  // ---- rho * G and x_c to the lane = row layout, through LDS (L is dead) ---------------------------------
+  lds_fence();
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + grp + 4 * r;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int c = 16 * cb + col;
+        if (row < n && c < n) M[row * n + c] = rho * X[I][cb][r];
+        if (row < n && c == n) vbuf[row] = X[I][cb][r];
+      }
+    }
+  }
+  lds_fence();
+  const bool isvar = lane < n;
+  const int lr = isvar ? lane : 0;
+  xc = isvar ? vbuf[lr] : 0.0;
+  if constexpr (n % 2 == 0) {
+    const lds_d2 *g2 = reinterpret_cast<const lds_d2 *>(M + lr * n);
+#pragma unroll
+    for (int jp = 0; jp < n / 2; ++jp) {
+      const d2 g = g2[jp];
+      Mrow[2 * jp] = isvar ? g.x : 0.0;
+      Mrow[2 * jp + 1] = isvar ? g.y : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < n; ++jj) Mrow[jj] = isvar ? M[lr * n + jj] : 0.0;
+  }
+  lds_fence();
+}
+
 // Left-looking panel LDL^T, in place in LDS.  On return M holds L below the diagonal, the
 // diagonal slots hold 1/d (0 where |d| <= DBL_MIN: Eigen's LDLT::solve rule) and dvec holds d.
 // Returns true if a pivot was zero or not finite (where Eigen's info() can fail).
@@ -636,7 +838,11 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     // right-hand sides: lanes < n take unit vectors, lane n takes [-b; b_eq] out of vbuf
     stage_rhs();
     const long long t3 = wall_clock64();
+#ifdef FCCQP_P3_VALU
     P3<SH>::run(M, vbuf, lane, isvar, a, Mrow, xc);
+#else
+    p3_mfma<SH>(M, vbuf, lane, a.rho, Mrow, xc);
+#endif
     const long long t4 = wall_clock64();
     ph_p3 = t4 - t3;
 

@@ -49,27 +49,10 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
 
 
-#: shapes with a fused kernel (must match the instantiations in csrc/fccqp_fused.hip)
-FUSED_SHAPES = [(60, 38), (12, 5)]
-
-
-def generate_p3(force: bool = False) -> List[str]:
-    """Run csrc/gen_p3.py: phase P3 of the fused kernel as straight-line code, one file per shape."""
-    gen = os.path.join(CSRC, "gen_p3.py")
-    outs = []
-    for n, m in FUSED_SHAPES:
-        inc = os.path.join(CSRC, f"fccqp_p3_{n}_{m}.inc")
-        if force or _newer(inc, [gen]):
-            _run([sys.executable, gen, str(n), str(m), inc])
-        outs.append(inc)
-    return outs
-
-
 def build_lib(force: bool = False) -> str:
-    incs = generate_p3(force)
     srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip",
                                             "fccqp_fused_f32.hip")]
-    deps = srcs + incs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
+    deps = srcs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
                           os.path.join(CSRC, "fccqp_cod_impl.h"),
                           os.path.join(ROOT, "include", "fccqp.h")]
     if force or _newer(LIB, deps):
@@ -82,7 +65,7 @@ def build_lib(force: bool = False) -> str:
                       "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
                       "-Wno-unused-variable", "-c", src, "-o", obj])
 
-        # the translation units are independent (the fused kernel's two take ~1.5 min each)
+        # the translation units are independent
         with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as pool:
             list(pool.map(compile_one, zip(srcs, objs)))
         _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)

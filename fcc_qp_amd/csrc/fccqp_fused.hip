@@ -2,7 +2,6 @@
 // (fccqp_fused_impl.h).  Shapes compiled in:
 //   walking  FCCQP(60, 38, 12, 38)   reference harness shape, /root/reference/fcc_qp_test.py:77
 //   mini     FCCQP(12, 5, 6, 3)      small shape that exercises the same template in the tests
-// Phase P3 of each shape is generated by gen_p3.py into fccqp_p3_<n>_<m>.inc (build.py runs it).
 // Compiled twice: as is (Q / A_eq stored as double) and through fccqp_fused_f32.hip (as float).
 #include "fccqp_fused_impl.h"
 
@@ -10,47 +9,6 @@ namespace fccqp {
 using Walking = fused::Shape<60, 38, 12, 38>;
 using Mini = fused::Shape<12, 5, 6, 3>;
 
-namespace fused {
-template <>
-struct P3<Walking> {
-  static __device__ __forceinline__ void run(const lds_f64 *M, lds_f64 *vbuf, const int lane,
-                                             const bool isvar, const KernelArgs &a,
-                                             double (&Mrow)[Walking::n], double &xc) {
-    constexpr int n = Walking::n;
-    const lds_d2 *M2 = reinterpret_cast<const lds_d2 *>(M);
-#define FCCQP_P3_DECLARE
-#include "fccqp_p3_60_38.inc"
-#undef FCCQP_P3_DECLARE
-    lds_fence();
-#define FCCQP_P3_BODY
-#include "fccqp_p3_60_38.inc"
-#undef FCCQP_P3_BODY
-#define FCCQP_P3_EXTRACT
-#include "fccqp_p3_60_38.inc"
-#undef FCCQP_P3_EXTRACT
-  }
-};
-
-template <>
-struct P3<Mini> {
-  static __device__ __forceinline__ void run(const lds_f64 *M, lds_f64 *vbuf, const int lane,
-                                             const bool isvar, const KernelArgs &a,
-                                             double (&Mrow)[Mini::n], double &xc) {
-    constexpr int n = Mini::n;
-    const lds_d2 *M2 = reinterpret_cast<const lds_d2 *>(M);
-#define FCCQP_P3_DECLARE
-#include "fccqp_p3_12_5.inc"
-#undef FCCQP_P3_DECLARE
-    lds_fence();
-#define FCCQP_P3_BODY
-#include "fccqp_p3_12_5.inc"
-#undef FCCQP_P3_BODY
-#define FCCQP_P3_EXTRACT
-#include "fccqp_p3_12_5.inc"
-#undef FCCQP_P3_EXTRACT
-  }
-};
-}  // namespace fused
 
 namespace {
 // One storage type per translation unit.  With the float and double instantiations in the same

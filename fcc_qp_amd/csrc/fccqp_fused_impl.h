@@ -11,11 +11,18 @@
 //   * only 256 of the 512 registers per lane are VALU-addressable (the rest are AGPRs), so the
 //     98x98 KKT cannot live in registers: it lives in LDS (packed lower triangle, 39 KB) and is
 //     factorised in place; registers hold one 16-column panel at a time.
-//   * an operand every lane needs (same-address ds_read) costs 2 LDS cycles per double per CU;
-//     v_readlane costs ~9 cycles per double.  Broadcast operands therefore come from LDS as
-//     16-byte pairs, and the left-looking panel form reuses each lane-private operand 16 times.
-//   * fp64 MFMA has the same 78.6 TFLOP/s peak as the fp64 VALU on gfx950 and the per-QP blocks
-//     are triangular 98x98 updates and 60x60 mat-vecs, not contractions: no MFMA.
+//   * an operand every lane needs (same-address ds_read) costs 2 LDS cycles per double per CU
+//     (the return path moves 16 B x 64 lanes for 16 useful bytes); v_readlane costs ~9 cycles per
+//     double.  Broadcast-fed VALU loops (lane = row, or lane = right-hand side) were the first
+//     version of the factorisation's bulk update and of P3 and were LDS-bound at half the FMA rate.
+//   * fp64 MFMA (v_mfma_f64_16x16x4) has the same 78.6 TFLOP/s peak as the fp64 VALU, so it buys
+//     no flops -- but it takes its operands ONE ELEMENT PER LANE (a plain lane-distinct
+//     ds_read_b64, no broadcast), it leaves no lanes idle in triangular panels, and an
+//     accumulator tile can be fed straight back as the next product's B operand.  The two real
+//     contractions of the path, the (rows x c0)(c0 x 16) bulk update of a panel and the
+//     98 x 98 triangular solve with 64 right-hand sides of P3, therefore run on the matrix cores;
+//     everything sequential (in-panel pivots, the single-vector presolve, the 60 x 60 mat-vec of
+//     an ADMM iteration) stays on the VALU.
 //
 // Phases, N = n + m (walking shape: n = 60, m = 38, N = 98):
 //   P0  assemble the lower triangle of K = [[Q (+rho I), A^T],[A, 0]] in LDS (coalesced 16-byte
@@ -23,17 +30,18 @@
 //   P1  presolve, skipped on warm start (fcc_qp.cpp:159): LDL^T of K, solve for [-b; b_eq] -> x0.
 //   P2  K_rho assembled again and factorised (fcc_qp.cpp:62-68).
 //       Factorisation = unpivoted LDL^T in natural order, left-looking by panels of 16 columns:
-//       lane l owns rows l and 64+l; a panel's columns sit in registers, every earlier column q
-//       contributes  T[i][j] -= (L[i][q] d_q) * L[j][q]  with L[i][q] a lane-private LDS read and
-//       L[j][q], j in the panel, eight broadcast 16-byte reads.  L overwrites K; 1/d_j (with
-//       Eigen's pseudo-inverse rule) is kept on the diagonal.
-//   P3  61 right-hand sides at once, one per lane (e_0..e_{n-1} and [-b; b_eq]): forward / D /
-//       backward substitution with L streamed out of LDS as broadcast operands.  Lane l ends up
-//       holding row l of G = (K_rho^-1)[0:n,0:n]; lane n holds x_c = (K_rho^-1 [-b; b_eq])[0:n].
+//       the contribution of all earlier columns is one MFMA product per 16 x 16 row block, in
+//       place in LDS (mfma_bulk); then lane l owns rows l and 64+l of the panel in registers and
+//       the 16 pivots are eliminated with v_readlane-broadcast multipliers (factor_panel).  L
+//       overwrites K; 1/d_j (with Eigen's pseudo-inverse rule) is kept on the diagonal.
+//   P3  G = (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n]: blocked forward / D^-1 /
+//       backward substitution of the 98 x 64 block [e_0 .. e_{n-1} | -b; b_eq | 0] held in MFMA
+//       accumulator tiles (p3_mfma), then through LDS to the layout of P4: lane l holds row l
+//       of rho G and x_c[l].
 //   P4  ADMM iterations (fcc_qp.cpp:79-110): the KKT solve of an iteration is
 //       x = x_c + (rho G) w,  w = x_bar - mu_x (lambda_c segment overwritten, fcc_qp.cpp:82):
 //       a 60x60 mat-vec with w broadcast through LDS; projections, residuals, dual update and the
-//       exit test are per-lane work plus two DPP wave reductions.
+//       exit test are per-lane work plus one ballot.
 //   P5  epilogue metrics (fcc_qp.cpp:184-186) and write-back of z and the warm-start state.
 //
 // Pivot order: natural (no pivoting).  K_rho is symmetric quasi-definite, so the factorisation
@@ -175,13 +183,6 @@ struct Shape {
 
 };
 
-// Phase P3 is generated per shape by gen_p3.py (straight-line code; see there for why) and
-// plugged in through this trait (specialised in fccqp_fused.hip): run() turns the factorisation in
-// M into this lane's row of rho * G (Mrow) and its entry of x_c (xc).
-//   static void run(const lds_f64 *M, lds_f64 *vbuf, int lane, bool isvar, const KernelArgs &a,
-//                   double (&Mrow)[n], double &xc);
-template <class SH>
-struct P3;
 
 // Bulk update of a panel on the matrix cores.  For the 16 columns c0..c0+15 and every row >= c0,
 //   K[i][j] -= sum_{q < c0} (L[i][q] d_q) L[j][q]
@@ -277,14 +278,22 @@ __device__ __forceinline__ void invert_diag_blocks(lds_f64 *M, const int lane) {
     double y[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) y[i] = (i == j) ? 1.0 : 0.0;
+    // column k of this lane's block starts at colp[k] (row r0): rows are immediate offsets.  Dead
+    // lanes and rows / columns past N-1 read in-bounds garbage that is masked to zero.
+    const lds_f64 *colp[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+      const int c = (live && r0 + k < N) ? r0 + k : 0;
+      colp[k] = M + SH::cbase(c) + (live ? r0 : 0);
+    }
+    const int nrow = live ? N - r0 : 0;                             // valid rows in this block
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
+      double l[15];
 #pragma unroll
-      for (int k = 0; k < i; ++k) {
-        const bool ok = live && (r0 + i < N);                       // column r0 + k < row r0 + i < N
-        const double l = ok ? M[SH::cbase(ok ? r0 + k : 0) + (ok ? r0 + i : 0)] : 0.0;
-        y[i] = fma(-l, y[k], y[i]);
-      }
+      for (int k = 0; k < i; ++k) l[k] = colp[k][i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) y[i] = fma(-((i < nrow) ? l[k] : 0.0), y[k], y[i]);
     }
     lds_fence();   // every lane has read its block before any lane overwrites one
 #pragma unroll
@@ -838,11 +847,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     // right-hand sides: lanes < n take unit vectors, lane n takes [-b; b_eq] out of vbuf
     stage_rhs();
     const long long t3 = wall_clock64();
-#ifdef FCCQP_P3_VALU
-    P3<SH>::run(M, vbuf, lane, isvar, a, Mrow, xc);
-#else
     p3_mfma<SH>(M, vbuf, lane, a.rho, Mrow, xc);
-#endif
     const long long t4 = wall_clock64();
     ph_p3 = t4 - t3;
 

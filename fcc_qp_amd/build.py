@@ -61,9 +61,11 @@ def build_lib(force: bool = False) -> str:
         def compile_one(job):
             src, obj = job
             if force or _newer(obj, deps):
+                # the fully unrolled MFMA tile code (up to 13 row blocks) is larger than LLVM's default
+                # budget for `#pragma unroll`; left partly rolled it indexes register arrays dynamically
                 _run([hipcc(), "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-                      "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-                      "-Wno-unused-variable", "-c", src, "-o", obj])
+                      "-fno-gpu-rdc", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=400000",
+                      "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-c", src, "-o", obj])
 
         # the translation units are independent
         with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as pool:

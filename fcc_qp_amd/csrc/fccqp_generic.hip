@@ -692,6 +692,237 @@ __device__ __forceinline__ void g_build_batch(const lds_f64 *M, const int N, con
   }
 }
 
+// ---- G build on the matrix cores (four-wave workgroups) ---------------------------------------------
+// Same scheme as p3_mfma of the fused kernel (fccqp_fused_impl.h), with runtime N: the N x 128 block
+// X = [e_0 .. e_{n-1} | -b; b_eq | 0 ..] is split by column blocks of 16 over the four waves (two
+// each); a wave keeps its N x 32 slice in MFMA accumulator tiles and runs the blocked forward /
+// D^-1 / backward substitution on it: X_I -= L_IK X_K with A[i][k] = L[16I+i][16K+4r+k] one
+// ds_read_b64 per lane and B = accumulator register r of tile X_K as it stands.  The 16 x 16 diagonal
+// blocks of L are inverted in place first (all waves, one column per lane).  NRB = ceil(N / 16) is
+// a template parameter so that the tiles have compile-time register indices.
+using d4 = double __attribute__((ext_vector_type(4)));
+
+// all waves: column j of the inverse of diagonal block blk, for pair p = 16 blk + j
+__device__ __forceinline__ void invert_diag_blocks_share(lds_f64 *M, const int N, const int p) {
+  const int nrb = (N + 15) / 16;
+  const int blk = p >> 4, j = p & 15, r0 = 16 * blk;
+  const bool live = blk < nrb;
+  double y[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) y[i] = (i == j) ? 1.0 : 0.0;
+  const lds_f64 *colp[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    const int c = (live && r0 + k < N) ? r0 + k : 0;
+    colp[k] = M + col_base(c, N) + (live ? r0 : 0);
+  }
+  const int nrow = live ? N - r0 : 0;
+#pragma unroll
+  for (int i = 1; i < 16; ++i) {
+    double l[15];
+#pragma unroll
+    for (int k = 0; k < i; ++k) l[k] = colp[k][i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) y[i] = fma(-((i < nrow) ? l[k] : 0.0), y[k], y[i]);
+  }
+  __syncthreads();   // every lane of every wave has read its block before any block is overwritten
+#pragma unroll
+  for (int i = 1; i < 16; ++i)
+    if (live && i > j && r0 + i < N) M[col_base(r0 + j, N) + r0 + i] = y[i];
+  __syncthreads();
+}
+
+// A real call (noinline): inlined into the solver wave, its ~400 live registers push the solver's own
+// state into scratch for the whole kernel (measured: 2.2 KB of scratch per lane, every phase slower).
+// Arguments of a real call arrive in VGPRs; v_readfirstlane makes the wave-uniform ones scalar again.
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T>
+__device__ __forceinline__ T *uni_p(T *p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double uni_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+template <int NRB>
+__device__ __noinline__ void g_build_mfma(lds_f64 *M_in, const int N_in, const int n_in, const int lane,
+                                          const int wave_in, const double rho_in, double *stage_in,
+                                          const lds_f64 *rhs_in, lds_f64 *xc_in) {
+  constexpr int NCB = 2, NT = 4 * NRB, TC = 8;         // A operands are fetched TC k-steps at a time
+  const int N = uni_i(N_in), n = uni_i(n_in), wave = uni_i(wave_in);
+  const double rho = uni_d(rho_in);
+  lds_f64 *const M = (lds_f64 *)(size_t)(unsigned)uni_i((int)(unsigned)(size_t)M_in);
+  const lds_f64 *const rhs_s = (const lds_f64 *)(size_t)(unsigned)uni_i((int)(unsigned)(size_t)rhs_in);
+  lds_f64 *const xc_s = (lds_f64 *)(size_t)(unsigned)uni_i((int)(unsigned)(size_t)xc_in);
+  double *const stage = uni_p(stage_in);
+  const int col = lane & 15, grp = lane >> 4;
+  d4 X[NRB][NCB];
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + grp + 4 * r;
+      const double rhs = (row < N) ? rhs_s[row < N ? row : 0] : 0.0;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int c = 32 * wave + 16 * cb + col;
+        X[I][cb][r] = (c < n) ? ((row == c) ? 1.0 : 0.0) : ((c == n) ? rhs : 0.0);
+      }
+    }
+  }
+  // forward operand L[16I + col][4t + grp]: column base recomputed per k-step (a table of 4 NRB
+  // pointers per lane is what pushed the inlined version over the register file)
+  auto fwd_at = [&](const int t, const int I) -> double {
+    const int c = (4 * t + grp < N) ? 4 * t + grp : N - 1;
+    return M[col_base(c, N) + col + 16 * I];            // rows past N-1 land in allocated LDS
+  };
+  const lds_f64 *bwd[NRB];
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) bwd[I] = M + col_base((16 * I + col < N) ? 16 * I + col : N - 1, N) + grp;
+  // ---- forward ------------------------------------------------------------------------------------
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+    d4 T[NCB];                                          // the diagonal product accumulates separately
+#pragma unroll
+    for (int ch = 0; ch < (NT + TC - 1) / TC; ++ch) {
+      const int t0 = ch * TC;
+      double aop[TC];
+#pragma unroll
+      for (int u = 0; u < TC; ++u) {
+        const int t = t0 + u;
+        if (t < 4 * I + 4) {
+          const double v = fwd_at(t, I);
+          bool keep = (16 * I + col < N) && (4 * t + grp < N);
+          if (t >= 4 * I) keep = keep && (col > 4 * (t - 4 * I) + grp);   // inverted diagonal block: strict lower
+          aop[u] = keep ? ((t >= 4 * I) ? v : -v) : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TC; ++u) {
+        const int t = t0 + u;
+        if (t < 4 * I) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], X[t / 4][cb][t % 4], X[I][cb], 0, 0, 0);
+        } else if (t < 4 * I + 4) {
+          if (t == 4 * I) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) T[cb] = X[I][cb];
+          }
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            T[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], X[I][cb][t - 4 * I], T[cb], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) X[I][cb] = T[cb];
+  }
+  // ---- D^-1, Eigen's pseudo-inverse rule (the diagonal slots hold d) --------------------------------
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + grp + 4 * r;
+      const int rc = (row < N) ? row : 0;
+      const double d = M[col_base(rc, N) + rc];
+      const double rd = (row < N && fabs(d) > DBL_MIN) ? 1.0 / d : 0.0;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) X[I][cb][r] *= rd;
+    }
+  }
+  // ---- backward: the diagonal product first needs all K > I applied, so it comes last -----------------
+#pragma unroll
+  for (int Ir = 0; Ir < NRB; ++Ir) {
+    const int I = NRB - 1 - Ir;
+#pragma unroll
+    for (int ch = 0; ch < (NT + TC - 1) / TC; ++ch) {
+      const int t0 = 4 * I + 4 + ch * TC;
+      double aop[TC];
+#pragma unroll
+      for (int u = 0; u < TC; ++u) {
+        const int t = t0 + u;
+        if (t < NT) {
+          const double v = bwd[I][4 * t];               // L[4t + grp][16I + col]
+          const bool keep = (16 * I + col < N) && (4 * t + grp < N);
+          aop[u] = keep ? -v : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TC; ++u) {
+        const int t = t0 + u;
+        if (t < NT) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], X[t / 4][cb][t % 4], X[I][cb], 0, 0, 0);
+        }
+      }
+    }
+    double dop[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = 4 * I + r;
+      const double v = bwd[I][4 * t];
+      const bool keep = (16 * I + col < N) && (4 * t + grp < N) && (4 * r + grp > col);
+      dop[r] = keep ? v : 0.0;
+    }
+    d4 T[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) T[cb] = X[I][cb];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        T[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(dop[r], X[I][cb][r], T[cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) X[I][cb] = T[cb];
+  }
+  // ---- rho * G columns to the staging matrix, x_c to LDS ---------------------------------------------
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + grp + 4 * r;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int c = 32 * wave + 16 * cb + col;
+        if (row < n && c < n) stage[(size_t)c * n + row] = rho * X[I][cb][r];
+        if (row < n && c == n) xc_s[row] = X[I][cb][r];
+      }
+    }
+  }
+}
+
+// the whole cooperative build between barriers A and B of the kCmdBuild command; false if this
+// shape is not covered (then the caller falls back to the readlane batches)
+__device__ __forceinline__ bool g_build_mfma_supported(const int N, const int n) {
+  const int nrb = (N + 15) / 16;
+  return n + 1 <= 128 && nrb >= 9 && nrb <= 13;
+}
+template <int SLOTS>
+__device__ __forceinline__ void g_build_mfma_share(lds_f64 *M, const int N, const int n, const int lane,
+                                                   const int wave, const double rho, double *stage,
+                                                   lds_f64 *scratch) {
+  invert_diag_blocks_share(M, N, wave * kWave + lane);
+  const lds_f64 *rhs_s = scratch;
+  lds_f64 *xc_s = scratch + N;
+  const int nrb = (N + 15) / 16;
+  if constexpr (SLOTS == 3) {
+    if (nrb == 9) g_build_mfma<9>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+    else if (nrb == 10) g_build_mfma<10>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+    else if (nrb == 11) g_build_mfma<11>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+    else if (nrb == 12) g_build_mfma<12>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+  } else {
+    if (nrb == 13) g_build_mfma<13>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+  }
+}
+
 // waves 1..WAVES-1 of a multi-wave workgroup, for one instance
 template <int SLOTS, int WAVES, class TIN>
 __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, const int wave, const int lane) {
@@ -729,8 +960,12 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       continue;
     }
     double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
-    for (int b = wave; b * RB <= n; b += WAVES)
-      g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
+    if (g_build_mfma_supported(N, n)) {
+      g_build_mfma_share<SLOTS>(M, N, n, lane, wave, a.rho, stage, (lds_f64 *)ctrl + kCtrlWords);
+    } else {
+      for (int b = wave; b * RB <= n; b += WAVES)
+        g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();                                   // B: every column of G is staged, L is dead
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -923,17 +1158,42 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
         if (use_g && iter == gswitch) {
           double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
           if constexpr (WAVES > 1) {
+            if (g_build_mfma_supported(N, n)) {        // [-b; b_eq] where every wave can read it
+              lds_f64 *rhs_s = ctrl_word(lds, N, nc) + kCtrlWords;
+#pragma unroll
+              for (int t = 0; t < SLOTS; ++t) {
+                const int i = lane + kWave * t;
+                if (i < N) rhs_s[i] = (i < n) ? -vb[t] : vtail[t];
+              }
+            }
             if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdBuild;
             __syncthreads();                           // A (see helper_wave)
           }
-          g_build_batch<SLOTS, RB, true>(M, N, n, lane, 0, a.rho, stage, vb, vtail, xc);
-          for (int b = WAVES; b * RB <= n; b += WAVES)
-            g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
+          bool by_mfma = false;
+          if constexpr (WAVES > 1) by_mfma = g_build_mfma_supported(N, n);
+          if constexpr (WAVES > 1) {
+            if (by_mfma) g_build_mfma_share<SLOTS>(M, N, n, lane, 0, a.rho, stage, ctrl_word(lds, N, nc) + kCtrlWords);
+          }
+          if (!by_mfma) {
+            g_build_batch<SLOTS, RB, true>(M, N, n, lane, 0, a.rho, stage, vb, vtail, xc);
+            for (int b = WAVES; b * RB <= n; b += WAVES)
+              g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
+          }
           // the staged columns are read back by other lanes (and waves)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           if constexpr (WAVES > 1) __syncthreads();    // B
           else wave_sync();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if constexpr (WAVES > 1) {
+            if (by_mfma) {                             // x_c came back through LDS
+              const lds_f64 *xc_s = ctrl_word(lds, N, nc) + kCtrlWords + N;
+#pragma unroll
+              for (int t = 0; t < GS; ++t) {
+                const int i = lane + kWave * t;
+                xc[t] = (i < n) ? xc_s[i] : 0.0;
+              }
+            }
+          }
           const int total = n * n;
 #pragma unroll 8
           for (int e = lane; e < total; e += WAVES * kWave) M[g_off + e] = stage[e];
@@ -1186,7 +1446,8 @@ size_t generic_lds_bytes(int n, int m, int nc) {
   const size_t N = (size_t)n + m;
   // + one panel of slack: the last panel's broadcast reads run up to 15 rows past the matrix
   // + the command words of the multi-wave workgroups (ctrl_word)
-  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel + kCtrlWords);
+  // + 2N doubles of scratch for the MFMA G build ([-b; b_eq] in, x_c out)
+  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel + kCtrlWords + 2 * N);
 }
 
 long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {

@@ -124,10 +124,10 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
 
 constexpr int kPanel = 16;
 constexpr int kGSwitchIter = 16;       // ADMM iterations by triangular sweeps before G is built ...
-constexpr int kGSwitchIterMulti = 8;   // ... when four waves share the build (it is ~3x cheaper)
+constexpr int kGSwitchIterMulti = 4;   // ... when four waves share the build on the matrix cores
 // G is only built if at least this many iterations can still follow (the build costs about that
 // many sweep iterations: it cannot pay off under a small max_iter, e.g. the paper's 15)
-constexpr int kGMinRemaining = 32, kGMinRemainingMulti = 16;
+constexpr int kGMinRemaining = 32, kGMinRemainingMulti = 12;
 using d2 = double __attribute__((ext_vector_type(2)));
 using lds_d2 = __attribute__((address_space(3))) d2;
 
@@ -797,9 +797,12 @@ __device__ __noinline__ void g_build_mfma(lds_f64 *M_in, const int N_in, const i
         const int t = t0 + u;
         if (t < 4 * I + 4) {
           const double v = fwd_at(t, I);
-          bool keep = (16 * I + col < N) && (4 * t + grp < N);
+          // 16 (NRB - 1) < N <= 16 NRB: only the last row block / its k-steps can leave the matrix
+          bool keep = true;
+          if (I == NRB - 1) keep = keep && (16 * I + col < N);
+          if (t >= 4 * (NRB - 1)) keep = keep && (4 * t + grp < N);
           if (t >= 4 * I) keep = keep && (col > 4 * (t - 4 * I) + grp);   // inverted diagonal block: strict lower
-          aop[u] = keep ? ((t >= 4 * I) ? v : -v) : 0.0;
+          aop[u] = (I == NRB - 1 || t >= 4 * (NRB - 1) || t >= 4 * I) ? (keep ? ((t >= 4 * I) ? v : -v) : 0.0) : -v;
         }
       }
 #pragma unroll
@@ -849,8 +852,10 @@ __device__ __noinline__ void g_build_mfma(lds_f64 *M_in, const int N_in, const i
         const int t = t0 + u;
         if (t < NT) {
           const double v = bwd[I][4 * t];               // L[4t + grp][16I + col]
-          const bool keep = (16 * I + col < N) && (4 * t + grp < N);
-          aop[u] = keep ? -v : 0.0;
+          bool keep = true;
+          if (I == NRB - 1) keep = keep && (16 * I + col < N);
+          if (t >= 4 * (NRB - 1)) keep = keep && (4 * t + grp < N);
+          aop[u] = (I == NRB - 1 || t >= 4 * (NRB - 1)) ? (keep ? -v : 0.0) : -v;
         }
       }
 #pragma unroll
@@ -868,7 +873,8 @@ __device__ __noinline__ void g_build_mfma(lds_f64 *M_in, const int N_in, const i
     for (int r = 0; r < 4; ++r) {
       const int t = 4 * I + r;
       const double v = bwd[I][4 * t];
-      const bool keep = (16 * I + col < N) && (4 * t + grp < N) && (4 * r + grp > col);
+      bool keep = (4 * r + grp > col);
+      if (I == NRB - 1) keep = keep && (16 * I + col < N) && (4 * t + grp < N);
       dop[r] = keep ? v : 0.0;
     }
     d4 T[NCB];

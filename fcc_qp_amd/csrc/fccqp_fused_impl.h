@@ -356,12 +356,17 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
         aop[t] = 0.0;
       }
     }
+    // In the forward sweep tile X_K of column block cb is still all zero while every unit entry of
+    // the block lies below row block K (columns 16 cb .. are e_c with c >= 16 cb); the block that
+    // holds the dense column [-b; b_eq] (c == n) is the exception.  Those products are skipped.
+    auto zero_tile = [](int K, int cb) { return K < cb && cb != n / 16; };
 #pragma unroll
     for (int t = 0; t < 4 * I; ++t) {
       if (4 * t < N) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
-          X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[t], X[t / 4][cb][t % 4], X[I][cb], 0, 0, 0);
+          if (!zero_tile(t / 4, cb))
+            X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[t], X[t / 4][cb][t % 4], X[I][cb], 0, 0, 0);
       }
     }
     // X_I = L_II^-1 X_I = X_I + (strictly lower part of the inverted block) X_I
@@ -373,7 +378,8 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
       if (4 * (4 * I + r) < N) {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
-          T[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[4 * I + r], X[I][cb][r], T[cb], 0, 0, 0);
+          if (!zero_tile(I, cb))
+            T[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[4 * I + r], X[I][cb][r], T[cb], 0, 0, 0);
       }
     }
 #pragma unroll

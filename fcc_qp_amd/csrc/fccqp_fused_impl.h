@@ -195,11 +195,14 @@ struct Shape {
 // the panel's own columns in LDS, so the rest of factor_panel (load, in-panel step, write-back)
 // is unchanged.  Layouts (cdna_hip_programming.md): C/D col = lane & 15, row = (lane >> 4) + 4 r.
 using d4 = double __attribute__((ext_vector_type(4)));
-template <class SH>
-__device__ __forceinline__ void mfma_bulk(lds_f64 *M, const lds_f64 *dvec, const int lane, const int c0) {
+// RB0 = c0 / 16, the first row block that holds rows >= c0, is a template parameter: with a
+// run-time `rb >= rb0` around every tile the compiler turns the fetch-then-MFMA structure back into
+// load / wait / MFMA triples behind branches.
+template <class SH, int RB0>
+__device__ __forceinline__ void mfma_bulk_rb(lds_f64 *M, const lds_f64 *dvec, const int lane) {
   constexpr int N = SH::N, NRB = (N + 15) / 16;
+  constexpr int rb0 = RB0, c0 = 16 * RB0;
   const int col = lane & 15, grp = lane >> 4;
-  const int rb0 = c0 >> 4;                               // first row block that holds rows >= c0
   const int j = (c0 + col < N) ? c0 + col : N - 1;       // this lane's panel column (clamped)
   const int cbj = SH::cbase(j);
   d4 acc[NRB];
@@ -251,6 +254,22 @@ __device__ __forceinline__ void mfma_bulk(lds_f64 *M, const lds_f64 *dvec, const
     }
   }
   lds_fence();
+}
+
+template <class SH>
+__device__ __forceinline__ void mfma_bulk(lds_f64 *M, const lds_f64 *dvec, const int lane, const int c0) {
+  constexpr int NRB = (SH::N + 15) / 16;
+  static_assert(NRB <= 8, "dispatch below covers eight row blocks");
+  switch (c0 >> 4) {
+    case 1: if constexpr (NRB > 1) mfma_bulk_rb<SH, 1>(M, dvec, lane); break;
+    case 2: if constexpr (NRB > 2) mfma_bulk_rb<SH, 2>(M, dvec, lane); break;
+    case 3: if constexpr (NRB > 3) mfma_bulk_rb<SH, 3>(M, dvec, lane); break;
+    case 4: if constexpr (NRB > 4) mfma_bulk_rb<SH, 4>(M, dvec, lane); break;
+    case 5: if constexpr (NRB > 5) mfma_bulk_rb<SH, 5>(M, dvec, lane); break;
+    case 6: if constexpr (NRB > 6) mfma_bulk_rb<SH, 6>(M, dvec, lane); break;
+    case 7: if constexpr (NRB > 7) mfma_bulk_rb<SH, 7>(M, dvec, lane); break;
+    default: break;
+  }
 }
 
 // ---- P3 on the matrix cores ------------------------------------------------------------------------

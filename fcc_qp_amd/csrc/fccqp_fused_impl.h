@@ -247,9 +247,13 @@ __device__ __forceinline__ void mfma_bulk_rb(lds_f64 *M, const lds_f64 *dvec, co
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * rb + grp + 4 * r;
-        // on or below the diagonal of an existing column only: above it the address belongs to the
-        // previous column's tail
-        if (row < N && c0 + col < N && row >= c0 + col) M[cbj + row] = acc[rb][r];
+        // on or below the diagonal of an existing column only (above it the address belongs to the
+        // previous column's tail); which tiles can violate which condition is known statically
+        bool ok = true;
+        if (rb == rb0) ok = ok && (row >= c0 + col);
+        if (16 * rb + 15 >= N) ok = ok && (row < N);
+        if (c0 + 15 >= N) ok = ok && (c0 + col < N);
+        if (ok) M[cbj + row] = acc[rb][r];
       }
     }
   }

@@ -260,21 +260,6 @@ __device__ __forceinline__ void mfma_bulk_rb(lds_f64 *M, const lds_f64 *dvec, co
   lds_fence();
 }
 
-template <class SH>
-__device__ __forceinline__ void mfma_bulk(lds_f64 *M, const lds_f64 *dvec, const int lane, const int c0) {
-  constexpr int NRB = (SH::N + 15) / 16;
-  static_assert(NRB <= 8, "dispatch below covers eight row blocks");
-  switch (c0 >> 4) {
-    case 1: if constexpr (NRB > 1) mfma_bulk_rb<SH, 1>(M, dvec, lane); break;
-    case 2: if constexpr (NRB > 2) mfma_bulk_rb<SH, 2>(M, dvec, lane); break;
-    case 3: if constexpr (NRB > 3) mfma_bulk_rb<SH, 3>(M, dvec, lane); break;
-    case 4: if constexpr (NRB > 4) mfma_bulk_rb<SH, 4>(M, dvec, lane); break;
-    case 5: if constexpr (NRB > 5) mfma_bulk_rb<SH, 5>(M, dvec, lane); break;
-    case 6: if constexpr (NRB > 6) mfma_bulk_rb<SH, 6>(M, dvec, lane); break;
-    case 7: if constexpr (NRB > 7) mfma_bulk_rb<SH, 7>(M, dvec, lane); break;
-    default: break;
-  }
-}
 
 // ---- P3 on the matrix cores ------------------------------------------------------------------------
 // X := (L D L^T)^-1 X for the N x 64 block X = [e_0 .. e_{n-1} | -b; b_eq | 0 ..]: a triangular
@@ -501,14 +486,17 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
 // compiled twice (USE0: rows < 64 take part / only rows >= 64 do) instead of branching inside,
 // columns are addressed by a running offset, loads are unmasked (rows above the diagonal pick
 // up garbage that is never stored) and the panel is written back once at the end.
-template <class SH, bool USE0>
-__device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const int lane, const int c0) {
-  constexpr int N = SH::N, P = kPanel;
+// C0, the panel's first column, is a template parameter: every column base, the diagonal block's
+// lane window and the short-last-panel masks become constants (one instantiation per panel).
+template <class SH, int C0>
+__device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const int lane) {
+  constexpr int N = SH::N, P = kPanel, c0 = C0;
+  constexpr bool USE0 = C0 < kWave;
   const int row0 = lane, row1 = kWave + lane;
   const int r0c = (row0 < N) ? row0 : N - 1;   // clamped rows: in-bounds reads for idle lanes
   const int r1c = (row1 < N) ? row1 : N - 1;
   // (b) first: the contribution of every earlier column, on the matrix cores, in place in LDS
-  if (c0 > 0) mfma_bulk<SH>(M, dvec, lane, c0);
+  if constexpr (C0 > 0) mfma_bulk_rb<SH, C0 / 16>(M, dvec, lane);
   double T0[P], T1[P];
   // (a) panel columns into registers
 #pragma unroll
@@ -595,10 +583,9 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
 template <class SH>
 __device__ __forceinline__ bool factor_lds(lds_f64 *M, lds_f64 *dvec, const int lane) {
   bool bad = false;
-#pragma nounroll
-  for (int c0 = 0; c0 < SH::N && c0 < kWave; c0 += kPanel) bad |= factor_panel<SH, true>(M, dvec, lane, c0);
-#pragma nounroll
-  for (int c0 = kWave; c0 < SH::N; c0 += kPanel) bad |= factor_panel<SH, false>(M, dvec, lane, c0);
+  static_for<0, (SH::N + kPanel - 1) / kPanel>([&](auto pc) {
+    bad |= factor_panel<SH, kPanel * decltype(pc)::value>(M, dvec, lane);
+  });
   return bad;
 }
 

@@ -230,13 +230,14 @@ __device__ __forceinline__ void mfma_bulk_rb(lds_f64 *M, const lds_f64 *dvec, co
       if (rb >= rb0) acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[rb] * o.nd, o.b, acc[rb], 0, 0, 0);
   };
   {
+    // fully unrolled (c0 is a template constant): the column bases become per-lane constants + offsets
     Ops oa, ob;
     fetch(0, oa);
-#pragma nounroll
+#pragma unroll
     for (int q0 = 0; q0 < c0; q0 += 8) {
       fetch(q0 + 4, ob);
       apply(oa);
-      fetch((q0 + 8 < c0) ? q0 + 8 : q0 + 4, oa);        // last trip: a harmless re-read
+      if (q0 + 8 < c0) fetch(q0 + 8, oa);
       apply(ob);
     }
   }

@@ -605,7 +605,7 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
   // ---- forward, unit lower: x_i -= L[i][k] x_k, i > k ----------------------------------------
   {
     int cb = SH::cbase(0);
-#pragma nounroll
+#pragma unroll
     for (int k0 = 0; k0 < NA; k0 += U) {   // x_k from slot 0; both slots have rows below
       double a0[U], a1[U];
       int cbu = cb;
@@ -626,7 +626,7 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
     }
     if constexpr (N > kWave) {
       cb = SH::cbase(kWave);
-#pragma nounroll
+#pragma unroll
       for (int k0 = kWave; k0 < N; k0 += U) {   // x_k from slot 1; only slot 1 has rows below
         double a1[U];
         int cbu = cb;
@@ -650,7 +650,7 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
   if constexpr (N > kWave) x1 *= M[cb1 + r1c];
   // ---- backward with L^T: x_i -= L[k][i] x_k, i < k (row k of L: a gather along lane columns) --
   if constexpr (N > kWave) {
-#pragma nounroll
+#pragma unroll
     for (int k0 = N - 1; k0 >= kWave; k0 -= U) {   // x_k from slot 1; slot 0 rows are all above
       double a0[U], a1[U];
 #pragma unroll
@@ -669,7 +669,7 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
       }
     }
   }
-#pragma nounroll
+#pragma unroll
   for (int k0 = NA - 1; k0 >= 1; k0 -= U) {   // x_k from slot 0; only slot 0 has rows above
     double a0[U];
 #pragma unroll

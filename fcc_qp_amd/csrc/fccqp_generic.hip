@@ -1452,8 +1452,10 @@ size_t generic_lds_bytes(int n, int m, int nc) {
   const size_t N = (size_t)n + m;
   // + one panel of slack: the last panel's broadcast reads run up to 15 rows past the matrix
   // + the command words of the multi-wave workgroups (ctrl_word)
-  // + 2N doubles of scratch for the MFMA G build ([-b; b_eq] in, x_c out)
-  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel + kCtrlWords + 2 * N);
+  // four-wave shapes (N > 128): + 2N doubles of scratch for the MFMA G build ([-b; b_eq] in, x_c
+  // out).  Not for the one-wave shapes: the walking shape fits four workgroups per CU by < 1 KB.
+  const size_t scratch = (N > 2 * kWave) ? 2 * N : 0;
+  return sizeof(double) * ((size_t)packed_doubles((int)N) + (size_t)nc + 2 + kPanel + kCtrlWords + scratch);
 }
 
 long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {

@@ -641,6 +641,14 @@ __device__ __forceinline__ void matvec_range(const lds_f64 *M, const int n, cons
   }
 }
 
+// Shape tags: DynShape reads the sizes from the kernel arguments (any shape); FixShape bakes one
+// shape in, so that column bases, loop bounds and edge masks fold into constants (what took the
+// fused kernel's factorisation from 84 to 58 us).  The large benchmark shape has an instantiation.
+struct DynShape { static constexpr bool fixed = false; static constexpr int n = 0, m = 0, nc = 0, s = 0; };
+template <int N_VARS, int N_EQ, int NC, int LC_START>
+struct FixShape { static constexpr bool fixed = true; static constexpr int n = N_VARS, m = N_EQ, nc = NC, s = LC_START; };
+using LargeShape = FixShape<114, 60, 24, 66>;
+
 // ---- building rho*G with several waves ----------------------------------------------------------
 // Shapes that need three or four register slots own a whole CU's LDS (one workgroup per CU), so
 // their workgroup is launched with four waves, one per SIMD: wave 0 runs the solver, waves 1-3
@@ -930,19 +938,19 @@ __device__ __forceinline__ void g_build_mfma_share(lds_f64 *M, const int N, cons
 }
 
 // waves 1..WAVES-1 of a multi-wave workgroup, for one instance
-template <int SLOTS, int WAVES, class TIN>
+template <int SLOTS, int WAVES, class TIN, class SHP>
 __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, const int wave, const int lane) {
   constexpr int RB = g_batch<SLOTS>();
-  const int n = a.n, N = a.n + a.m;
+  const int n = SHP::fixed ? SHP::n : a.n, N = SHP::fixed ? SHP::n + SHP::m : a.n + a.m;
   lds_f64 *M = (lds_f64 *)lds;
-  volatile lds_f64 *ctrl = ctrl_word(lds, N, a.nc);
+  volatile lds_f64 *ctrl = ctrl_word(lds, N, SHP::fixed ? SHP::nc : a.nc);
   for (;;) {
     __syncthreads();                                   // A: a command is posted
     const int cmd = (int)ctrl[0];
     if (cmd == kCmdDone) break;
     if (cmd == kCmdAssemble) {
       const TIN *Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
-      const TIN *A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * a.m * n;
+      const TIN *A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * (N - n) * n;
       assemble_share<TIN>(M, Q, A, n, N, (double)ctrl[1], lane, wave, WAVES);
       __syncthreads();                                 // B: the matrix is complete
       continue;
@@ -984,10 +992,11 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
 
 // Solves instance `inst`.  x0_given: the presolve was done elsewhere (fallback pass): x0 comes from
 // a.x, the duals start at zero, the presolve flags are reported as "ran, numerical, COD".
-template <int SLOTS, bool MAT_IN_LDS, class TIN>
+template <int SLOTS, bool MAT_IN_LDS, class TIN, class SHP>
 __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst, const bool x0_given) {
   const int lane = threadIdx.x;
-  const int n = a.n, m = a.m, nc = a.nc, s0 = a.s, N = n + m;
+  const int n = SHP::fixed ? SHP::n : a.n, m = SHP::fixed ? SHP::m : a.m, nc = SHP::fixed ? SHP::nc : a.nc,
+            s0 = SHP::fixed ? SHP::s : a.s, N = n + m;
   const int npack = packed_doubles(N);
 
   // matrix: LDS (ds_* instructions) or the per-block global workspace (global_* instructions)
@@ -1372,7 +1381,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   }
 }
 
-template <int SLOTS, bool MAT_IN_LDS, class TIN>
+template <int SLOTS, bool MAT_IN_LDS, class TIN, class SHP = DynShape>
 __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void generic_kernel(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
@@ -1381,13 +1390,13 @@ __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void gene
   auto run = [&](const int inst, const bool from_list) {
     if (wave == 0) {
       if (from_list) cod::cod_presolve<TIN>(a, inst, a.cod_ws + (long long)blockIdx.x * a.cod_stride);   // fcc_qp.cpp:165,176
-      solve_instance<SLOTS, MAT_IN_LDS, TIN>(a, lds, inst, from_list);
+      solve_instance<SLOTS, MAT_IN_LDS, TIN, SHP>(a, lds, inst, from_list);
       if constexpr (WAVES > 1) {
-        if (lane == 0) ctrl_word(lds, a.n + a.m, a.nc)[0] = (double)kCmdDone;
+        if (lane == 0) ctrl_word(lds, SHP::fixed ? SHP::n + SHP::m : a.n + a.m, SHP::fixed ? SHP::nc : a.nc)[0] = (double)kCmdDone;
         __syncthreads();
       }
     } else {
-      if constexpr (WAVES > 1) helper_wave<SLOTS, WAVES, TIN>(a, lds, inst, wave, lane);
+      if constexpr (WAVES > 1) helper_wave<SLOTS, WAVES, TIN, SHP>(a, lds, inst, wave, lane);
     }
   };
   if (a.inst_list) {  // list mode (fallback launch): persistent blocks walk the fallback list
@@ -1410,6 +1419,10 @@ hipError_t launch_slots(const KernelArgs &a, bool mat_in_lds, size_t lds_bytes, 
   }
   if (mat_in_lds) {
     auto k = generic_kernel<(SLOTS > 4 ? 4 : SLOTS), true, TIN>;
+    if constexpr (SLOTS == 3) {
+      if (a.n == LargeShape::n && a.m == LargeShape::m && a.nc == LargeShape::nc && a.s == LargeShape::s)
+        k = generic_kernel<3, true, TIN, LargeShape>;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;

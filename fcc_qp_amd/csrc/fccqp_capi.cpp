@@ -149,7 +149,8 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
       // LDS-resident shapes: per-instance staging for rho*G (n*n doubles), through which the
       // generic kernel switches long-running instances from triangular sweeps to a mat-vec
       // (fccqp_generic.hip); allocated on the first generic launch only
-      const size_t nn = (size_t)s->n * (size_t)s->n;
+      // + 2 (n + m): [-b; b_eq] in, x_c out for the one-wave MFMA build
+      const size_t nn = (size_t)s->n * (size_t)s->n + 2 * ((size_t)s->n + (size_t)s->m);
       if (dmalloc(&s->dwork, (size_t)s->batch * nn) == hipSuccess) {
         s->work_stride = (long long)nn;
         a.workspace = s->dwork; a.workspace_stride = s->work_stride;

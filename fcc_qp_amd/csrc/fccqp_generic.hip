@@ -710,7 +710,9 @@ __device__ __forceinline__ void g_build_batch(const lds_f64 *M, const int N, con
 // a template parameter so that the tiles have compile-time register indices.
 using d4 = double __attribute__((ext_vector_type(4)));
 
-// all waves: column j of the inverse of diagonal block blk, for pair p = 16 blk + j
+// column j of the inverse of diagonal block blk, for pair p = 16 blk + j (MULTI: all four waves of
+// a workgroup take part, else the one wave calls it once per 64 pairs)
+template <bool MULTI>
 __device__ __forceinline__ void invert_diag_blocks_share(lds_f64 *M, const int N, const int p) {
   const int nrb = (N + 15) / 16;
   const int blk = p >> 4, j = p & 15, r0 = 16 * blk;
@@ -733,11 +735,12 @@ __device__ __forceinline__ void invert_diag_blocks_share(lds_f64 *M, const int N
 #pragma unroll
     for (int k = 0; k < i; ++k) y[i] = fma(-((i < nrow) ? l[k] : 0.0), y[k], y[i]);
   }
-  __syncthreads();   // every lane of every wave has read its block before any block is overwritten
+  // every lane (of every wave) has read its block before any block is overwritten
+  if constexpr (MULTI) __syncthreads(); else wave_sync();
 #pragma unroll
   for (int i = 1; i < 16; ++i)
     if (live && i > j && r0 + i < N) M[col_base(r0 + j, N) + r0 + i] = y[i];
-  __syncthreads();
+  if constexpr (MULTI) __syncthreads(); else wave_sync();
 }
 
 // A real call (noinline): inlined into the solver wave, its ~400 live registers push the solver's own
@@ -757,16 +760,20 @@ __device__ __forceinline__ double uni_d(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int NRB>
+// RX: where [-b; b_eq] comes from and x_c goes to: LDS words (four-wave workgroups) or global memory
+// (one-wave workgroups, whose LDS has no room to spare).  `wave` picks the 32 right-hand-side columns.
+__device__ __forceinline__ lds_f64 *uni_ptr(lds_f64 *p) { return (lds_f64 *)(size_t)(unsigned)uni_i((int)(unsigned)(size_t)p); }
+__device__ __forceinline__ double *uni_ptr(double *p) { return uni_p(p); }
+template <int NRB, class RX>
 __device__ __noinline__ void g_build_mfma(lds_f64 *M_in, const int N_in, const int n_in, const int lane,
                                           const int wave_in, const double rho_in, double *stage_in,
-                                          const lds_f64 *rhs_in, lds_f64 *xc_in) {
+                                          RX *rhs_in, RX *xc_in) {
   constexpr int NCB = 2, NT = 4 * NRB, TC = 8;         // A operands are fetched TC k-steps at a time
   const int N = uni_i(N_in), n = uni_i(n_in), wave = uni_i(wave_in);
   const double rho = uni_d(rho_in);
   lds_f64 *const M = (lds_f64 *)(size_t)(unsigned)uni_i((int)(unsigned)(size_t)M_in);
-  const lds_f64 *const rhs_s = (const lds_f64 *)(size_t)(unsigned)uni_i((int)(unsigned)(size_t)rhs_in);
-  lds_f64 *const xc_s = (lds_f64 *)(size_t)(unsigned)uni_i((int)(unsigned)(size_t)xc_in);
+  const RX *const rhs_s = uni_ptr(rhs_in);
+  RX *const xc_s = uni_ptr(xc_in);
   double *const stage = uni_p(stage_in);
   const int col = lane & 15, grp = lane >> 4;
   d4 X[NRB][NCB];
@@ -923,17 +930,42 @@ template <int SLOTS>
 __device__ __forceinline__ void g_build_mfma_share(lds_f64 *M, const int N, const int n, const int lane,
                                                    const int wave, const double rho, double *stage,
                                                    lds_f64 *scratch) {
-  invert_diag_blocks_share(M, N, wave * kWave + lane);
-  const lds_f64 *rhs_s = scratch;
+  invert_diag_blocks_share<true>(M, N, wave * kWave + lane);
+  lds_f64 *rhs_s = scratch;
   lds_f64 *xc_s = scratch + N;
   const int nrb = (N + 15) / 16;
   if constexpr (SLOTS == 3) {
-    if (nrb == 9) g_build_mfma<9>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
-    else if (nrb == 10) g_build_mfma<10>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
-    else if (nrb == 11) g_build_mfma<11>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
-    else if (nrb == 12) g_build_mfma<12>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+    if (nrb == 9) g_build_mfma<9, lds_f64>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+    else if (nrb == 10) g_build_mfma<10, lds_f64>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+    else if (nrb == 11) g_build_mfma<11, lds_f64>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+    else if (nrb == 12) g_build_mfma<12, lds_f64>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
   } else {
-    if (nrb == 13) g_build_mfma<13>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+    if (nrb == 13) g_build_mfma<13, lds_f64>(M, N, n, lane, wave, rho, stage, rhs_s, xc_s);
+  }
+}
+
+// One-wave workgroups (N <= 128): the same build, the wave taking the 32-column slices one after
+// the other; [-b; b_eq] and x_c travel through `gs` (2 N doubles of global memory behind the staging
+// matrix).
+__device__ __forceinline__ bool g_build_mfma_single_supported(const int N, const int n, const long long stride) {
+  const int nrb = (N + 15) / 16;
+  return nrb >= 2 && nrb <= 8 && n + 1 <= 128 && stride >= (long long)n * n + 2 * N;
+}
+__device__ __forceinline__ void g_build_mfma_single(lds_f64 *M, const int N, const int n, const int lane,
+                                                    const double rho, double *stage, double *gs) {
+  const int nrb = (N + 15) / 16;
+  for (int p0 = 0; p0 < 16 * nrb; p0 += kWave) invert_diag_blocks_share<false>(M, N, p0 + lane);
+  const int parts = (n + 1 + 31) / 32;
+  for (int part = 0; part < parts; ++part) {
+    switch (nrb) {
+      case 2: g_build_mfma<2, double>(M, N, n, lane, part, rho, stage, gs, gs + N); break;
+      case 3: g_build_mfma<3, double>(M, N, n, lane, part, rho, stage, gs, gs + N); break;
+      case 4: g_build_mfma<4, double>(M, N, n, lane, part, rho, stage, gs, gs + N); break;
+      case 5: g_build_mfma<5, double>(M, N, n, lane, part, rho, stage, gs, gs + N); break;
+      case 6: g_build_mfma<6, double>(M, N, n, lane, part, rho, stage, gs, gs + N); break;
+      case 7: g_build_mfma<7, double>(M, N, n, lane, part, rho, stage, gs, gs + N); break;
+      default: g_build_mfma<8, double>(M, N, n, lane, part, rho, stage, gs, gs + N); break;
+    }
   }
 }
 
@@ -1153,14 +1185,17 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     constexpr int GS = (SLOTS < 2) ? SLOTS : 2;        // register slots that hold variables (n <= 128)
     constexpr int RB = g_batch<SLOTS>();
     constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
-    const int gswitch = (WAVES > 1) ? kGSwitchIterMulti : kGSwitchIter;
+    bool single_mfma = false;
+    if constexpr (MAT_IN_LDS && WAVES == 1)
+      single_mfma = a.workspace != nullptr && g_build_mfma_single_supported(N, n, a.workspace_stride);
+    const int gswitch = (WAVES > 1 || single_mfma) ? kGSwitchIterMulti : kGSwitchIter;
     // LDS doubles after the switch: rho*G [n][n] (column-major) | w [w_len], zero-padded | partial sums
     const int g_off = 0, w_off = g_w_off(n), w_len = g_w_len(n);
     bool use_g = false, g_ready = false;
     if constexpr (MAT_IN_LDS && SLOTS <= 4) {
       use_g = a.workspace != nullptr && n <= 2 * kWave && n > 0 && w_off + w_len <= npack &&
               a.workspace_stride >= (long long)n * n &&
-              a.max_iter - gswitch >= ((WAVES > 1) ? kGMinRemainingMulti : kGMinRemaining);
+              a.max_iter - gswitch >= ((WAVES > 1 || single_mfma) ? kGMinRemainingMulti : kGMinRemaining);
     }
     const bool coop_mv = (WAVES > 1) && g_part_off(n) + WAVES * 2 * kWave <= npack;
     double xc[GS];
@@ -1189,6 +1224,21 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
           if constexpr (WAVES > 1) {
             if (by_mfma) g_build_mfma_share<SLOTS>(M, N, n, lane, 0, a.rho, stage, ctrl_word(lds, N, nc) + kCtrlWords);
           }
+          if constexpr (WAVES == 1) {
+            if (single_mfma) {
+              double *gs = stage + (size_t)n * n;
+#pragma unroll
+              for (int t = 0; t < SLOTS; ++t) {
+                const int i = lane + kWave * t;
+                if (i < N) gs[i] = (i < n) ? -vb[t] : vtail[t];
+              }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              wave_sync();
+              g_build_mfma_single(M, N, n, lane, a.rho, stage, gs);
+              by_mfma = true;
+            }
+          }
           if (!by_mfma) {
             g_build_batch<SLOTS, RB, true>(M, N, n, lane, 0, a.rho, stage, vb, vtail, xc);
             for (int b = WAVES; b * RB <= n; b += WAVES)
@@ -1206,6 +1256,15 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               for (int t = 0; t < GS; ++t) {
                 const int i = lane + kWave * t;
                 xc[t] = (i < n) ? xc_s[i] : 0.0;
+              }
+            }
+          } else {
+            if (by_mfma) {                             // ... or through the staging buffer
+              const double *xc_g = stage + (size_t)n * n + N;
+#pragma unroll
+              for (int t = 0; t < GS; ++t) {
+                const int i = lane + kWave * t;
+                xc[t] = (i < n) ? xc_g[i] : 0.0;
               }
             }
           }

@@ -83,7 +83,9 @@ def _random_qp(rng, n, m, nc, s, finite_bounds=True):
                                   (120, 76, 12, 100),   # 4 slots in LDS (N = 196): four waves, G batches of 8
                                   (128, 1, 3, 125),     # n exactly two slots wide
                                   (110, 45, 9, 60),     # N = 155: ten row blocks in the MFMA G build
-                                  (120, 65, 12, 100)])  # N = 185: twelve row blocks
+                                  (120, 65, 12, 100),   # N = 185: twelve row blocks
+                                  (50, 25, 6, 30),      # N = 75: five row blocks, one-wave MFMA G build
+                                  (60, 30, 9, 40)])     # N = 90: six row blocks
 def test_odd_shapes_match_oracle(oracle, dims):
     """Ragged sizes around the wavefront width (64) and the register-slot boundaries (128, 192)."""
     n, m, nc, s = dims

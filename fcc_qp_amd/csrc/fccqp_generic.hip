@@ -130,6 +130,66 @@ constexpr int kGSwitchIterMulti = 4;   // ... when four waves share the build on
 constexpr int kGMinRemaining = 32, kGMinRemainingMulti = 12;
 using d2 = double __attribute__((ext_vector_type(2)));
 using lds_d2 = __attribute__((address_space(3))) d2;
+using d4 = double __attribute__((ext_vector_type(4)));
+
+// Bulk update of a panel on the matrix cores, for one-wave workgroups (the scheme of mfma_bulk in
+// fccqp_fused_impl.h with runtime N): K[i][j] -= sum_{q < c0} (L[i][q] d_q) L[j][q] for the 16 panel
+// columns and every 16-row block at or below the panel, operands one element per lane, tiles read
+// from and written back to the panel's own columns.  RBMAX bounds the row blocks (4 per slot).
+template <int RBMAX>
+__device__ __forceinline__ void mfma_bulk_rt(lds_f64 *M, const int N, const int lane, const int c0) {
+  const int col = lane & 15, grp = lane >> 4;
+  const int rb0 = c0 >> 4, nrb = (N + 15) >> 4;
+  const int j = (c0 + col < N) ? c0 + col : N - 1;
+  const int cbj = col_base(j, N);
+  d4 acc[RBMAX];
+#pragma unroll
+  for (int rb = 0; rb < RBMAX; ++rb) {
+    if (rb >= rb0 && rb < nrb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[rb][r] = M[cbj + 16 * rb + grp + 4 * r];   // rows past N-1: garbage rows
+    }
+  }
+  struct Ops { double b, nd, av[RBMAX]; };
+  auto fetch = [&](const int q0, Ops &o) {
+    const int q = q0 + grp;
+    const int cq = col_base(q, N);
+    o.b = M[cq + c0 + col];                              // B[k][n] = L[c0 + n][q0 + k]
+    o.nd = -M[cq + q];                                   // the diagonal slot holds d_q
+#pragma unroll
+    for (int rb = 0; rb < RBMAX; ++rb)
+      if (rb >= rb0 && rb < nrb) o.av[rb] = M[cq + 16 * rb + col];
+  };
+  auto apply = [&](const Ops &o) {
+#pragma unroll
+    for (int rb = 0; rb < RBMAX; ++rb)
+      if (rb >= rb0 && rb < nrb)
+        acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[rb] * o.nd, o.b, acc[rb], 0, 0, 0);
+  };
+  {
+    Ops oa, ob;
+    fetch(0, oa);
+#pragma nounroll
+    for (int q0 = 0; q0 < c0; q0 += 8) {                 // c0 is a multiple of 16: steps pair up
+      fetch(q0 + 4, ob);
+      apply(oa);
+      fetch((q0 + 8 < c0) ? q0 + 8 : q0 + 4, oa);        // last trip: a harmless re-read
+      apply(ob);
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int rb = 0; rb < RBMAX; ++rb) {
+    if (rb >= rb0 && rb < nrb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rb + grp + 4 * r;
+        if (row < N && c0 + col < N && row >= c0 + col) M[cbj + row] = acc[rb][r];
+      }
+    }
+  }
+  wave_sync();
+}
 
 // One 16-column panel of the left-looking LDL^T (matrix in LDS), columns c0..c0+15, for a wave
 // whose lanes own rows lane + 64 t.  SD = c0 / 64 is the register slot the panel's diagonal block
@@ -155,6 +215,11 @@ __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int la
   for (int t = 0; t < NT; ++t) {
     const int row = lane + kWave * (SD + t);
     rc[t] = (row < N) ? row : N - 1;               // clamped: in-bounds reads for idle lanes
+  }
+  // one-wave workgroups with at most two slots: the bulk update runs on the matrix cores, in place
+  constexpr bool MFMA_BULK = !COOP && SLOTS <= 2;
+  if constexpr (MFMA_BULK) {
+    if (c0 > 0) mfma_bulk_rt<4 * SLOTS>(M, N, lane, c0);
   }
   double T[NT][P];
 #pragma unroll
@@ -206,7 +271,7 @@ __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int la
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       bulk(q0, q0 + P);
     }
-  } else {
+  } else if constexpr (!MFMA_BULK) {
     if (c0 > 0) bulk(0, c0);
   }
   const int lane0 = c0 & (kWave - 1);
@@ -708,8 +773,6 @@ __device__ __forceinline__ void g_build_batch(const lds_f64 *M, const int N, con
 // ds_read_b64 per lane and B = accumulator register r of tile X_K as it stands.  The 16 x 16 diagonal
 // blocks of L are inverted in place first (all waves, one column per lane).  NRB = ceil(N / 16) is
 // a template parameter so that the tiles have compile-time register indices.
-using d4 = double __attribute__((ext_vector_type(4)));
-
 // column j of the inverse of diagonal block blk, for pair p = 16 blk + j (MULTI: all four waves of
 // a workgroup take part, else the one wave calls it once per 64 pairs)
 template <bool MULTI>

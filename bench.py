@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU (metric: 4096)")
-    ap.add_argument("--workload", default="W-sat", choices=["W-sat", "W-mix", "W-easy"])
+    ap.add_argument("--workload", default="W-sat", choices=["W-sat", "W-mix", "W-easy", "W-psd"])
     ap.add_argument("--shape", default="walking", choices=["walking", "large"],
                     help="walking = FCCQP(60,38,12,38), the metric's shape; large = FCCQP(114,60,24,66), "
                          "BASELINE configs[3] (secondary: generic kernel, four waves per QP)")

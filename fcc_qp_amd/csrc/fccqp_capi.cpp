@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -83,9 +84,20 @@ int fail(fccqp_solver *s, int code, const char *what, hipError_t e = hipSuccess)
     if (e_ != hipSuccess) return fail((s), FCCQP_ERR_HIP, #call, e_); \
   } while (0)
 
+// FCCQP_DEBUG_POISON=1 in the environment fills every fresh device allocation with 0xFF bytes (NaN
+// as double): a kernel that reads memory it has not written then shows up as NaN in z instead of
+// depending on what the allocator handed back.
+bool poison_allocations() {
+  static const bool on = [] { const char *e = std::getenv("FCCQP_DEBUG_POISON"); return e && e[0] == '1'; }();
+  return on;
+}
+
 template <class T>
 hipError_t dmalloc(T **p, size_t count) {
-  return hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T));
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
+  if (e == hipSuccess && poison_allocations()) e = hipMemset(*p, 0xFF, bytes);
+  return e;
 }
 
 size_t n_mu(const fccqp_solver *s) { return (size_t)(s->nc / 3); }
@@ -127,7 +139,9 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   a.x = s->dx; a.mu_x = s->dmux; a.mu_lc = s->dmulc;
   a.n_iter = s->dniter; a.flags = s->dflags; a.metrics = s->dmetrics;
   a.factor_ticks = s->dticks; a.phase_ticks = s->dphase; a.workspace = s->dwork; a.workspace_stride = s->work_stride;
-  const bool fb = s->fallback && !s->warm_start;   // the presolve only runs on a cold start
+  // the presolve runs on a cold start, and on a warm one for an equality-only instance
+  // (fcc_qp.cpp:159), which needs nc == 0
+  const bool fb = s->fallback && (!s->warm_start || s->nc == 0);
   int *cnt = s->dfb_count + (s->solve_seq & 1u), *cnt_next = s->dfb_count + ((s->solve_seq + 1u) & 1u);
   a.fb_list = fb ? s->dfb_list : nullptr; a.fb_count = fb ? cnt : nullptr;
   a.inst_list = nullptr; a.inst_count = nullptr; a.next_count = nullptr;
@@ -138,6 +152,9 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   if (s->kernel_request == FCCQP_KERNEL_FUSED && !can_fuse)
     return fail(s, FCCQP_ERR_UNSUPPORTED,
                 "no fused kernel for this shape, or Q / A_eq not 16-byte aligned");
+  // the handle's state (warm-start vectors, fallback list, counters, workspace) is shared by every
+  // solve: a solve enqueued on another stream than the previous one waits for it on the device
+  if (s->solved && stream != s->last_stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev1, 0));
   HIP_TRY(s, hipEventRecord(s->ev0, stream));
   hipError_t e;
   if (want_fused && can_fuse) {
@@ -170,7 +187,12 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     b.fb_list = nullptr; b.fb_count = nullptr;
     b.inst_list = s->dfb_list; b.inst_count = cnt; b.next_count = cnt_next;
     e = fccqp::launch_generic_list(b, s->lds_limit, blocks, stream, qa_f32);
-    if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "fallback kernel launch", e);
+    if (e != hipSuccess) {
+      // the main kernel may have appended to `cnt`, and nothing will consume it: start the next
+      // solve from a clean pair of counters
+      (void)hipMemsetAsync(s->dfb_count, 0, 2 * sizeof(int), stream);
+      return fail(s, FCCQP_ERR_HIP, "fallback kernel launch", e);
+    }
     s->solve_seq++;
   }
   HIP_TRY(s, hipEventRecord(s->ev1, stream));
@@ -324,6 +346,10 @@ int fccqp_set_presolve_fallback(fccqp_solver *s, int enabled) {
 }
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {
   if (!s || !kernel_in_use) return FCCQP_ERR_INVALID_ARG;
+  if (s->solved) {   // what the last solve ran (unaligned Q / A_eq fall back to the generic kernel)
+    *kernel_in_use = s->kernel_used;
+    return FCCQP_OK;
+  }
   const bool fuse = s->kernel_request != FCCQP_KERNEL_GENERIC &&
                     fccqp::fused_supported(s->n, s->m, s->nc, s->s);
   *kernel_in_use = fuse ? FCCQP_KERNEL_FUSED : FCCQP_KERNEL_GENERIC;

@@ -40,7 +40,9 @@ __device__ __forceinline__ double wmax(double v) {
   return v;
 }
 __device__ __forceinline__ void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // agent scope: the lanes exchange data through the global workspace (see global_phase_sync in
+  // fccqp_generic.hip for why the wavefront-scope fence is not relied on)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   __builtin_amdgcn_wave_barrier();
 }
 

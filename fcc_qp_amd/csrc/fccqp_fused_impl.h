@@ -25,29 +25,33 @@
 //     an ADMM iteration) stays on the VALU.
 //
 // Phases, N = n + m (walking shape: n = 60, m = 38, N = 98):
-//   P0  assemble the lower triangle of K = [[Q (+rho I), A^T],[A, 0]] in LDS (coalesced 16-byte
-//       reads of Q and A_eq; fcc_qp.cpp:146-150).
-//   P1  presolve, skipped on warm start (fcc_qp.cpp:159): LDL^T of K, solve for [-b; b_eq] -> x0.
-//   P2  K_rho assembled again and factorised (fcc_qp.cpp:62-68).
-//       Factorisation = unpivoted LDL^T in natural order, left-looking by panels of 16 columns:
-//       the contribution of all earlier columns is one MFMA product per 16 x 16 row block, in
-//       place in LDS (mfma_bulk); then lane l owns rows l and 64+l of the panel in registers and
-//       the 16 pivots are eliminated with v_readlane-broadcast multipliers (factor_panel).  L
-//       overwrites K; 1/d_j (with Eigen's pseudo-inverse rule) is kept on the diagonal.
+//   P0  assemble the lower triangle of K_rho = [[Q + rho I, A^T],[A, 0]] in LDS, ONCE (coalesced
+//       16-byte reads of Q and A_eq; fcc_qp.cpp:146-150,62-64).
+//   P1  factorise K_rho (fcc_qp.cpp:68): unpivoted LDL^T in natural order, left-looking by panels
+//       of 16 columns: the contribution of all earlier columns is one MFMA product per 16 x 16 row
+//       block, in place in LDS (mfma_bulk); then lane l owns rows l and 64+l of the panel in
+//       registers and the 16 pivots are eliminated with v_readlane-broadcast multipliers
+//       (factor_panel).  L overwrites K; 1/d_j (Eigen's pseudo-inverse rule) is kept on the diagonal.
 //   P3  G = (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n]: blocked forward / D^-1 /
 //       backward substitution of the 98 x 64 block [e_0 .. e_{n-1} | -b; b_eq | 0] held in MFMA
 //       accumulator tiles (p3_mfma), then through LDS to the layout of P4: lane l holds row l
 //       of rho G and x_c[l].
+//   Pw  presolve, skipped on warm start (fcc_qp.cpp:159-178): the reference's x0 = (K^-1 [-b; b_eq])
+//       .head(n) without a factorisation of K: x0 = (I - rho G)^-1 x_c (Woodbury; see the kernel
+//       body), an n x n panel LDL^T with the same code.  One assembly, one pass over HBM.
 //   P4  ADMM iterations (fcc_qp.cpp:79-110): the KKT solve of an iteration is
 //       x = x_c + (rho G) w,  w = x_bar - mu_x (lambda_c segment overwritten, fcc_qp.cpp:82):
 //       a 60x60 mat-vec with w broadcast through LDS; projections, residuals, dual update and the
 //       exit test are per-lane work plus one ballot.
 //   P5  epilogue metrics (fcc_qp.cpp:184-186) and write-back of z and the warm-start state.
 //
-// Pivot order: natural (no pivoting).  K_rho is symmetric quasi-definite, so the factorisation
-// exists in every symmetric order; the reference's Eigen LDLT orders pivots by the largest
-// remaining diagonal entry, which only reorders the same block elimination.  Parity with the
-// reference-order oracle is ~1e-13 relative on the walking-shape workloads.
+// Pivot order: natural (no pivoting).  For rho > 0, Q >= 0 and A_eq of full row rank K_rho is
+// symmetric quasi-definite ((1,1) block positive definite, Schur complement negative definite), so
+// the factorisation exists in every symmetric order; the reference's Eigen LDLT orders pivots by the
+// largest remaining diagonal entry, which only reorders the same block elimination.  A duplicated
+// equality row gives an exactly zero pivot with an exactly zero column, in Eigen as here; both drop
+// it (pseudo-inverse rule).  Parity with the reference-order oracle is ~1e-13 relative on the
+// walking-shape workloads.
 #pragma once
 #include <cfloat>
 #include <type_traits>
@@ -59,6 +63,10 @@ namespace fused {
 
 constexpr int kWave = 64;
 constexpr int kPanel = 16;
+// presolve: smallest pivot of W = I - rho G (eigenvalues in (0, 1]) still taken as non-singular.
+// A pivot p amplifies the ~1e-16 error of rho G by 1/p; below this the instance goes to the COD
+// fallback, whose minimum-norm solution is what the reference returns for a singular K.
+constexpr double kPresolveMinPivot = 1e-10;
 using d2 = double __attribute__((ext_vector_type(2)));
 // explicit LDS address space: keeps every access a ds_* instruction (a generic pointer decays to
 // flat_load / flat_store as soon as it goes through a select or a volatile cast)
@@ -159,15 +167,12 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
 // rounded quotient, a third of the dependent-instruction chain of an IEEE division.)
 
 // ---- compile-time shape description ------------------------------------------------------------
-template <int N_VARS, int N_EQ, int NC, int LC_START>
-struct Shape {
-  static constexpr int n = N_VARS, m = N_EQ, nc = NC, s = LC_START, N = N_VARS + N_EQ;
-  static_assert(n >= 1 && n < kWave, "one lane per variable plus one lane for the rhs column");
-  static_assert(N <= 2 * kWave, "two KKT rows per lane");
-  static_assert(nc % 3 == 0 && s + nc <= n, "fcc_qp.cpp:32-33");
-  // Packed lower triangle, column-major: element (i,j), i >= j, lives at cbase(j) + i.  Column
-  // starts are padded so that cbase(j) is even: an element's address parity is its row parity and
-  // ds_read_b128 of rows (2r, 2r+1) is always 16-byte aligned.
+// Packed lower triangle of an NN x NN symmetric matrix, column-major: element (i,j), i >= j, lives
+// at cbase(j) + i.  Column starts are padded so that cbase(j) is even: an element's address parity
+// is its row parity and ds_read_b128 of rows (2r, 2r+1) is always 16-byte aligned.
+template <int NN>
+struct Packed {
+  static constexpr int N = NN;
   static constexpr int cstart(int j) {
     return j * N - (j * (j - 1)) / 2 + ((N % 2 == 0) ? (j + 1) / 2 : j / 2);
   }
@@ -176,11 +181,26 @@ struct Shape {
   static constexpr int cstep(int j) { return N - j - 1 + (((j & 1) == (N & 1)) ? 1 : 0); }
   static constexpr int kMat = (cstart(N) + 1) & ~1;
   static constexpr int kNp = (N + 1) & ~1;
+};
+
+template <int N_VARS, int N_EQ, int NC, int LC_START>
+struct Shape : Packed<N_VARS + N_EQ> {
+  using KKT = Packed<N_VARS + N_EQ>;
+  using KKT::N; using KKT::kMat; using KKT::kNp;
+  // the n x n matrix W = I - rho G of the presolve (see fused_kernel) reuses the front of the image
+  using Reduced = Packed<N_VARS>;
+  static constexpr int n = N_VARS, m = N_EQ, nc = NC, s = LC_START;
+  static_assert(n >= 1 && n < kWave, "one lane per variable plus one lane for the rhs column");
+  static_assert(N <= 2 * kWave, "two KKT rows per lane");
+  static_assert(nc % 3 == 0 && s + nc <= n, "fcc_qp.cpp:32-33");
+  // nc == 0 with all-infinite bounds is the reference's equality-only case (fcc_qp.cpp:132-133: one
+  // direct solve, no ADMM); such shapes go to the generic kernel, which keeps the direct presolve
+  static_assert(nc > 0, "fused shapes have contacts");
   // LDS carve (doubles): matrix | dvec[kNp] | vbuf[max(kNp, 64)]
   static constexpr int kVbuf = (kNp > kWave) ? kNp : kWave;
   static constexpr int kLdsDoubles = kMat + kNp + kVbuf;
   static_assert(kLdsDoubles * 8 <= 160 * 1024 / 4, "four one-wave workgroups per CU");
-
+  static_assert(n * n <= kMat, "rho G (n x n, row-major) fits over the dead factor");
 };
 
 
@@ -493,6 +513,8 @@ template <class SH, int C0>
 __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const int lane) {
   constexpr int N = SH::N, P = kPanel, c0 = C0;
   constexpr bool USE0 = C0 < kWave;
+  constexpr bool USE1 = N > kWave;              // a second register slot exists (rows 64 + lane)
+  static_assert(USE0 || USE1, "panel past the matrix");
   const int row0 = lane, row1 = kWave + lane;
   const int r0c = (row0 < N) ? row0 : N - 1;   // clamped rows: in-bounds reads for idle lanes
   const int r1c = (row1 < N) ? row1 : N - 1;
@@ -505,7 +527,7 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
     const int j = (c0 + jj < N) ? c0 + jj : N - 1;
     const int cb = SH::cbase(j);
     T0[jj] = USE0 ? M[cb + r0c] : 0.0;
-    T1[jj] = M[cb + r1c];
+    T1[jj] = USE1 ? M[cb + r1c] : 0.0;
   }
   // (c) factorise the panel itself, column by column.  All 16 panel rows live in one register
   // slot (64 is a multiple of 16), so the multipliers l_{c0+jj, j} of the in-panel update are
@@ -517,19 +539,22 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
   const int ncol = (N - c0 < P) ? N - c0 : P;   // columns that exist (the last panel may be short)
   // the pivot of column k+1 is broadcast and inverted as soon as column k+1 has received step k's
   // update (the first one issued), so the reciprocal chain of the next step hides under the rest
-  // of this step's FMAs
+  // of this step's FMAs.  rinv is 0 for a pivot with |d| <= DBL_MIN: Eigen's LDLT leaves the column
+  // below a zero pivot alone (it is zero if the matrix is consistent, e.g. a duplicated equality
+  // row) and its solve() drops the pivot (pseudo-inverse rule); scaling by 0 does both.
+  auto pinv = [](double dd) { const double r = fast_rcp(dd); return (fabs(dd) > DBL_MIN) ? r : 0.0; };
   double d = bcast_lane(USE0 ? T0[0] : T1[0], lane0);
-  double rinv = fast_rcp(d);
+  double rinv = pinv(d);
 #pragma unroll
   for (int k = 0; k < P; ++k) {
     // zero, infinite or NaN pivot (class mask: sNaN|qNaN|-inf|-0|+0|+inf); columns past N in a
     // short last panel hold garbage that is computed on (no branch) but neither judged nor stored
     bad_any |= (k < ncol) & __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
     dmine = (rel == k) ? d : dmine;
-    rmine = (rel == k) ? ((fabs(d) > DBL_MIN) ? rinv : 0.0) : rmine;
+    rmine = (rel == k) ? rinv : rmine;
     const double a0 = T0[k], a1 = T1[k];
     if constexpr (USE0) T0[k] = a0 * rinv;
-    T1[k] = a1 * rinv;
+    if constexpr (USE1) T1[k] = a1 * rinv;
     const double lsrc = USE0 ? T0[k] : T1[k];
     // rank-1 update of the panel columns to the right:  T[i][jj] -= a_i * l_{c0+jj, j}.
     // The scalar for column jj+1 is read (v_readlane pair) before the FMAs of column jj, which
@@ -542,12 +567,13 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
     for (int jj = k + 1; jj < P; ++jj) {
       double lnext = (jj + 1 < P) ? bcast_lane(lsrc, lane0 + jj + 1) : 0.0;
       if constexpr (USE0) T0[jj] = fma(-a0, lcur, T0[jj]);
-      T1[jj] = fma(-a1, lcur, T1[jj]);
-      if constexpr (USE0) asm volatile("" : "+v"(T0[jj]), "+v"(T1[jj]), "+s"(lnext));
+      if constexpr (USE1) T1[jj] = fma(-a1, lcur, T1[jj]);
+      if constexpr (USE0 && USE1) asm volatile("" : "+v"(T0[jj]), "+v"(T1[jj]), "+s"(lnext));
+      else if constexpr (USE0) asm volatile("" : "+v"(T0[jj]), "+s"(lnext));
       else asm volatile("" : "+v"(T1[jj]), "+s"(lnext));
       if (jj == k + 1) {  // column k+1 is final: look ahead
         dn = bcast_lane(USE0 ? T0[jj] : T1[jj], lane0 + jj);
-        rn = fast_rcp(dn);
+        rn = pinv(dn);
       }
       lcur = lnext;
     }
@@ -561,10 +587,12 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
         if (k < ncol) M[SH::cbase(c0 + k) + row0] = T0[k];
     }
   }
-  if (row1 >= c0 + P && row1 < N) {
+  if constexpr (USE1) {
+    if (row1 >= c0 + P && row1 < N) {
 #pragma unroll
-    for (int k = 0; k < P; ++k)
-      if (k < ncol) M[SH::cbase(c0 + k) + row1] = T1[k];
+      for (int k = 0; k < P; ++k)
+        if (k < ncol) M[SH::cbase(c0 + k) + row1] = T1[k];
+    }
   }
   // ... the diagonal block's own rows only what lies strictly below the diagonal, plus d, 1/d
   {
@@ -726,14 +754,9 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   const int ccomp = is_cone ? (lane - s0) - 3 * cidx : 0;
   double x = 0.0;
   if (a.warm_start) x = isvar ? xs[lane] : 0.0;  // fcc_qp.cpp:136-139 (duals are fetched at P4)
-  bool equality_constrained = false;             // fcc_qp.cpp:132-133
-  if constexpr (nc == 0) {
-    const double l0 = isvar ? lbp[lane] : -HUGE_VAL, u0 = isvar ? ubp[lane] : HUGE_VAL;
-    equality_constrained = __all(!isvar || (isinf(l0) && isinf(u0)));
-  }
-  int flags = equality_constrained ? kFlagEqualityOnly : 0;
+  // nc > 0: never the reference's equality-only case (fcc_qp.cpp:132-133)
+  int flags = 0;
   long long ticks = 0;
-  const bool cold = equality_constrained || !a.warm_start;  // presolve runs (fcc_qp.cpp:159)
 
   // P0: lower triangle of [[Q + rho I, A^T],[A, 0]] into LDS; Q and A_eq are read front to back,
   // 16 bytes per lane (fcc_qp.cpp:146-150; only Q[i][j], i >= j, is used, like Eigen's Lower LDLT)
@@ -811,62 +834,80 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 
   int n_iter = 0;
   double x_res_norm = 0.0, lc_res_norm = 0.0;
-  // phase stamps (100 MHz): 0 assemble, 1 factor, 2 presolve solve, 3 P3, 4 P4, 5 total
-  long long ph_asm = 0, ph_asm1 = 0, ph_solve = 0, ph_p3 = 0, ph_p4 = 0;
+  // phase stamps (100 MHz): 0 assemble, 1 factor, 2 presolve (W), 3 P3, 4 P4, 5 total
+  long long ph_asm = 0, ph_solve = 0, ph_p3 = 0, ph_p4 = 0;
   const long long t_begin = wall_clock64();
 
-  // A cold start needs K twice (presolve on K, ADMM on K + rho I) and the in-place factorisation
-  // destroys it; the second assembly reads Q and A_eq again (L2 / Infinity-Cache hits mostly).
-  // Keeping the image on-chip across the presolve was tried four ways (plain register array,
-  // AGPR-class inline-asm values, a mix of both, hand-partitioned AGPRs under amdgpu_num_vgpr):
-  // the allocator either parks ~30 KB per wave in scratch -- more traffic than the re-read -- or
-  // ignores the partition.  Measured with a (wrong-result) hand-partitioned build: 0.91x
-  // algorithmic bytes instead of 1.43x and -6 us per QP; needs an assembly-level kernel.
-#pragma nounroll
-  for (int pass = cold ? 0 : 1; pass < 2; ++pass) {
-    if (pass == 1 && equality_constrained) break;
-    const long long ta = wall_clock64();
-    assemble(pass == 0 ? 0.0 : a.rho);  // P1: K (fcc_qp.cpp:146-150,161);  P2: K_rho (fcc_qp.cpp:62-64)
-    const long long t0 = wall_clock64();
-    ph_asm += t0 - ta;
-    if (pass == 1) ph_asm1 = t0 - ta;
-    const bool bad = factor_lds<SH>(M, dvec, lane);
-    ticks += wall_clock64() - t0;
-    if (pass == 0) {
-      flags |= kFlagPresolveRan | (bad ? kFlagPresolveNumerical : 0);
-      if (bad && a.fb_list) {
-        // where the reference switches to its COD fallback (fcc_qp.cpp:164-166): hand the instance
-        // to the fallback pass (fccqp_cod.hip + generic kernel in list mode) and stop here
-        if (lane == 0) {
-          a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
-          a.flags[inst] = flags;
-        }
-        return;
-      }
-      // x_ = (K^-1 [-b; b_eq]).head(n)   (fcc_qp.cpp:149-150,174)
-      stage_rhs();
-      double r0 = (lane < N) ? vbuf[lane < N ? lane : 0] : 0.0;
-      double r1 = (kWave + lane < N) ? vbuf[kWave + lane < N ? kWave + lane : 0] : 0.0;
-      lds_fence();
-      const long long ts = wall_clock64();
-      solve_lds<SH>(M, lane, r0, r1);
-      ph_solve += wall_clock64() - ts;
-      x = isvar ? r0 : 0.0;  // n < 64: the variables are rows 0..n-1 = lanes 0..n-1 of slot 0
-    } else if (bad) {
-      flags |= kFlagAdmmNumerical;  // info() is not checked by the reference here (cpp:68)
-    }
-  }
+  // ---- P0 + P1: K_rho = K + rho [I 0; 0 0], assembled and factorised ONCE (fcc_qp.cpp:62-68) ------
+  // The reference factorises twice on a cold start: K for the presolve x0 = (K^-1 [-b; b_eq]).head(n)
+  // (fcc_qp.cpp:159-178) and K_rho for the iterations.  Here x0 comes out of the K_rho factorisation
+  // (see "presolve" below), so Q and A_eq are read from HBM exactly once and the second N^3/3 is
+  // replaced by an n^3/3 one.
+  assemble(a.rho);
+  const long long t0 = wall_clock64();
+  ph_asm = t0 - t_begin;
+  if (factor_lds<SH>(M, dvec, lane)) flags |= kFlagAdmmNumerical;  // info() is not checked by the reference (cpp:68)
+  ticks = wall_clock64() - t0;
 
-  if (!equality_constrained) {
-    // ---- P3: G = (K_rho^-1)[0:n,0:n] and x_c, one right-hand side per lane -------------------
+  {
+    // ---- P3: rho G = rho (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n] -----------------
     double Mrow[n];
     double xc;
-    // right-hand sides: lanes < n take unit vectors, lane n takes [-b; b_eq] out of vbuf
     stage_rhs();
     const long long t3 = wall_clock64();
     p3_mfma<SH>(M, vbuf, lane, a.rho, Mrow, xc);
-    const long long t4 = wall_clock64();
+    long long t4 = wall_clock64();
     ph_p3 = t4 - t3;
+
+    // ---- presolve (fcc_qp.cpp:159-178; skipped on warm start) ----------------------------------------
+    // x0 = (K^-1 r).head(n), r = [-b; b_eq].  With E = [I_n; 0], K = K_rho - rho E E^T, and the
+    // Woodbury identity gives
+    //     x0 = (I - rho G)^-1 x_c,        G = E^T K_rho^-1 E,   x_c = E^T K_rho^-1 r
+    // (equivalently: x0 is the fixed point of the unconstrained iteration x = x_c + rho G x).
+    // W = I - rho G is symmetric, with eigenvalue 1 on range(A_eq^T) and lambda / (lambda + rho) for
+    // every eigenvalue lambda of the reduced Hessian Z^T Q Z: positive definite exactly when K is
+    // non-singular, and far better conditioned than K (cond <= 1 + rho / lambda_min).  It is
+    // factorised by the same panel LDL^T (n x n: n^3/3 instead of N^3/3 flops, no second assembly,
+    // no second pass over Q / A_eq in HBM).  Against the exact K^-1 r this x0 is accurate to ~1e-14
+    // relative on the walking workloads at the harness rho, ~1e-11 at rho = 0.1 (the direct
+    // unpivoted LDL^T of K: ~1e-13; tools/woodbury_presolve.py), and it exists for semi-definite
+    // costs with zero diagonal entries, where an unpivoted LDL^T of K breaks down and the
+    // reference's own pivoted one fails over to its COD (fcc_qp.cpp:164-166).  Where W is singular
+    // to working precision (a pivot <= kPresolveMinPivot: K is singular, the reference's COD gives
+    // the minimum-norm solution) the instance goes to the device COD fallback, as before.
+    if (!a.warm_start) {
+      using SW = typename SH::Reduced;
+      flags |= kFlagPresolveRan;
+      // W, packed lower, over the rho G image in LDS (row `lane` of rho G is in registers by now)
+#pragma unroll
+      for (int j = 0; j < n; ++j)
+        if (lane >= j && isvar) M[SW::cbase(j) + lane] = ((lane == j) ? 1.0 : 0.0) - Mrow[j];
+      lds_fence();
+      const long long tw = wall_clock64();
+      bool wbad = factor_lds<SW>(M, dvec, lane);
+      const double dw = dvec[isvar ? lane : 0];
+      wbad = wbad || __any(!(dw > kPresolveMinPivot));
+      ticks += wall_clock64() - tw;
+      if (wbad) {
+        flags |= kFlagPresolveNumerical;
+        if (a.fb_list) {
+          // hand the instance to the fallback pass (COD, fccqp_cod_impl.h + generic kernel in list
+          // mode) and stop here
+          if (lane == 0) {
+            a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
+            a.flags[inst] = flags;
+          }
+          return;
+        }
+      }
+      double r0 = xc, r1 = 0.0;
+      solve_lds<SW>(M, lane, r0, r1);
+      x = isvar ? r0 : 0.0;
+      lds_fence();
+      const long long t5 = wall_clock64();
+      ph_solve = t5 - t4;
+      t4 = t5;
+    }
 
     // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------
     const double vlb = isvar ? fresh(lbp)[lane] : -HUGE_VAL;
@@ -956,8 +997,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       // is one ballot instead of two wave reductions; the norms themselves (:97-98) are only
       // reported, and are reduced once after the loop.  An empty contact set has norm 0.
       bool ok = (var_i == 0) || (fabs(xr) < eps_b);
-      if constexpr (nc > 0) ok = ok && ((cone_i == 0) || (fabs(lr) < eps_f));
-      else ok = ok && (0.0 < eps_f);
+      ok = ok && ((cone_i == 0) || (fabs(lr) < eps_f));
       if (__all(ok)) {
         n_iter = iter;
         break;
@@ -966,14 +1006,12 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     if (a.max_iter > 0) {
       // :97-98  abs(max(maxCoeff, -minCoeff)) == max_i |r_i| of the last iteration executed
       x_res_norm = wave_max(isvar ? fabs(xr) : 0.0);
-      if constexpr (nc > 0) lc_res_norm = wave_max(is_cone ? fabs(lr) : 0.0);
+      lc_res_norm = wave_max(is_cone ? fabs(lr) : 0.0);
     }
     // duals are part of the warm-start state (fcc_qp.hpp:149-150)
     if (isvar) mux_s[lane] = mux;
     if (is_cone) mulc_s[lane - s0] = mulc;
     ph_p4 = wall_clock64() - t4;
-  } else if (!a.warm_start) {
-    if (isvar) mux_s[lane] = 0.0;  // mu_x_.setZero() (fcc_qp.cpp:136-139); nc == 0 here
   }
 
   // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back -----------------------------------------
@@ -1012,7 +1050,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       a.phase_ticks[3 * B + inst] = ph_p3;
       a.phase_ticks[4 * B + inst] = ph_p4;
       a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
-      a.phase_ticks[6 * B + inst] = ph_asm1;
+      a.phase_ticks[6 * B + inst] = ph_asm;
       a.phase_ticks[7 * B + inst] = t_begin;
     }
   }

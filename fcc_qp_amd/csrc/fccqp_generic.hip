@@ -45,6 +45,19 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Matrix in the per-block GLOBAL workspace (N > 198): the lanes of the wave hand matrix entries to each
+// other through memory, and the owner of an entry changes from phase to phase (assembly: lane =
+// column; factorisation: lane = row - k - 1; solves: lane = row).  Between phases the wave's writes
+// are pushed to L2 and its L1 lines dropped (agent-scope release + acquire: buffer_wbl2 / buffer_inv).
+// The wavefront-scope fence alone, which is all the memory model asks for inside one wave, gave
+// sporadically wrong results in the second phase of a solve on some MI355X boxes and not on others
+// (re-assembly over the presolve's factor, whose lines were still in L1; found by the N = 257..512
+// tests of tests/test_gpu_reference_quirks.py) -- measured, not explained.
+__device__ __forceinline__ void global_phase_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
   // src_lane is wave-uniform
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -206,9 +219,19 @@ __device__ __forceinline__ void mfma_bulk_rt(lds_f64 *M, const int N, const int 
 // (an LDS word) counts the finished panels, the bulk update is applied one earlier panel at a time
 // as soon as that panel is published, and the panel publishes itself at the end.  Owners of lower
 // panels never wait on higher ones, so the waits always terminate.
+//
+// tiny: a pivot with |d| <= tiny counts as a breakdown (returns true).  0 for the ADMM factorisation
+// (only an exactly zero / non-finite pivot is reported, as in Eigen's info()); for the unpivoted
+// presolve of the indefinite K it is N eps max|Q_ii|: in floating point a singular leading block
+// leaves a pivot of rounding-error size, not 0, and the columns divided by it are garbage -- the
+// reference's pivoted LDLT either survives such a matrix or fails over to its COD, so the instance
+// is handed to the fallback pass instead of being solved wrongly without a flag.
+// A pivot with |d| <= DBL_MIN scales its column by 0: Eigen's LDLT leaves the column below a zero
+// pivot alone (it is zero for a consistent matrix, e.g. a duplicated equality row) and solve()
+// drops the pivot (pseudo-inverse rule).
 template <int SLOTS, int SD, bool COOP>
 __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int lane, const int c0,
-                                           volatile lds_f64 *done) {
+                                           volatile lds_f64 *done, const double tiny) {
   constexpr int P = kPanel, NT = SLOTS - SD;
   int rc[NT];
 #pragma unroll
@@ -279,13 +302,14 @@ __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int la
   const int ncol = (N - c0 < P) ? N - c0 : P;
   bool bad_any = false;
   double dmine = 1.0;
+  auto pinv = [](double dd) { const double r = fast_rcp(dd); return (fabs(dd) > DBL_MIN) ? r : 0.0; };
   double d = lane_bcast(T[0][0], lane0);
-  double rinv = fast_rcp(d);
+  double rinv = pinv(d);
 #pragma unroll
   for (int k = 0; k < P; ++k) {
-    // zero, infinite or NaN pivot; columns past N in a short last panel hold garbage that is
+    // zero, tiny, infinite or NaN pivot; columns past N in a short last panel hold garbage that is
     // computed on (no branch) but neither judged nor stored
-    bad_any |= (k < ncol) & __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
+    bad_any |= (k < ncol) & (__builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200) | (fabs(d) <= tiny));
     dmine = (rel == k) ? d : dmine;
     double av[NT];
 #pragma unroll
@@ -302,7 +326,7 @@ __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int la
       asm volatile("" : "+v"(T[0][jj]), "+s"(lnext));
       if (jj == k + 1) {
         dn = lane_bcast(T[0][jj], lane0 + jj);
-        rn = fast_rcp(dn);
+        rn = pinv(dn);
       }
       lcur = lnext;
     }
@@ -335,71 +359,119 @@ __device__ __forceinline__ bool ldlt_panel(lds_f64 *M, const int N, const int la
 }
 
 template <int SLOTS>
-__device__ bool ldlt_factor(lds_f64 *M, int N, int lane) {
+__device__ bool ldlt_factor(lds_f64 *M, int N, int lane, const double tiny) {
   static_assert(SLOTS <= 4, "a matrix that fits in LDS has N <= 256");
   bool bad = false;
 #pragma nounroll
   for (int c0 = 0; c0 < N; c0 += kPanel) {
     const int sd = c0 >> 6;
-    if (sd == 0) bad |= ldlt_panel<SLOTS, 0, false>(M, N, lane, c0, nullptr);
-    if constexpr (SLOTS > 1) { if (sd == 1) bad |= ldlt_panel<SLOTS, 1, false>(M, N, lane, c0, nullptr); }
-    if constexpr (SLOTS > 2) { if (sd == 2) bad |= ldlt_panel<SLOTS, 2, false>(M, N, lane, c0, nullptr); }
-    if constexpr (SLOTS > 3) { if (sd == 3) bad |= ldlt_panel<SLOTS, 3, false>(M, N, lane, c0, nullptr); }
+    if (sd == 0) bad |= ldlt_panel<SLOTS, 0, false>(M, N, lane, c0, nullptr, tiny);
+    if constexpr (SLOTS > 1) { if (sd == 1) bad |= ldlt_panel<SLOTS, 1, false>(M, N, lane, c0, nullptr, tiny); }
+    if constexpr (SLOTS > 2) { if (sd == 2) bad |= ldlt_panel<SLOTS, 2, false>(M, N, lane, c0, nullptr, tiny); }
+    if constexpr (SLOTS > 3) { if (sd == 3) bad |= ldlt_panel<SLOTS, 3, false>(M, N, lane, c0, nullptr, tiny); }
   }
   return bad;
 }
 
 // The panels part, part + parts, ... of a factorisation shared by `parts` waves (see ldlt_panel).
 template <int SLOTS>
-__device__ bool ldlt_factor_share(lds_f64 *M, int N, int lane, int part, int parts, volatile lds_f64 *done) {
+__device__ bool ldlt_factor_share(lds_f64 *M, int N, int lane, int part, int parts, volatile lds_f64 *done,
+                                  const double tiny) {
   static_assert(SLOTS <= 4, "a matrix that fits in LDS has N <= 256");
   bool bad = false;
 #pragma nounroll
   for (int c0 = part * kPanel; c0 < N; c0 += parts * kPanel) {
     const int sd = c0 >> 6;
-    if (sd == 0) bad |= ldlt_panel<SLOTS, 0, true>(M, N, lane, c0, done);
-    if constexpr (SLOTS > 1) { if (sd == 1) bad |= ldlt_panel<SLOTS, 1, true>(M, N, lane, c0, done); }
-    if constexpr (SLOTS > 2) { if (sd == 2) bad |= ldlt_panel<SLOTS, 2, true>(M, N, lane, c0, done); }
-    if constexpr (SLOTS > 3) { if (sd == 3) bad |= ldlt_panel<SLOTS, 3, true>(M, N, lane, c0, done); }
+    if (sd == 0) bad |= ldlt_panel<SLOTS, 0, true>(M, N, lane, c0, done, tiny);
+    if constexpr (SLOTS > 1) { if (sd == 1) bad |= ldlt_panel<SLOTS, 1, true>(M, N, lane, c0, done, tiny); }
+    if constexpr (SLOTS > 2) { if (sd == 2) bad |= ldlt_panel<SLOTS, 2, true>(M, N, lane, c0, done, tiny); }
+    if constexpr (SLOTS > 3) { if (sd == 3) bad |= ldlt_panel<SLOTS, 3, true>(M, N, lane, c0, done, tiny); }
   }
   return bad;
 }
 
 // Unpivoted LDL^T in place (right-looking), natural order: the variant for matrices that do not
-// fit in LDS (global workspace).  Returns true if a pivot was zero or not finite (the situation
-// in which Eigen's info() != Success can arise, fcc_qp.cpp:164).
+// fit in LDS (global workspace, N > 198).  Returns true if a pivot was zero, not finite or, in
+// magnitude, <= tiny (the situation in which Eigen's info() != Success can arise, fcc_qp.cpp:164;
+// see ldlt_panel for `tiny`).
+//
+// Row ownership is static: lane l owns rows l, l + 64, ... of the matrix for the whole
+// factorisation, so every entry M[i][j] is read, updated and written back by ONE lane only, and
+// what the other lanes need of column k -- the unscaled a_jk, j > k -- travels through registers
+// (v_readlane), not through memory.  (The first version moved the lane <-> row map with k, i = k + 1 +
+// lane, handing every entry from lane to lane through global memory once per step under a
+// wavefront-scope fence; on some MI355X boxes, not on others, that returned sporadically wrong
+// factors for N > 256 -- found by tests/test_gpu_reference_quirks.py, cause not established.)
+// The trailing update is issued as groups of loads, FMAs and stores (U columns x the live slots):
+// left as read-modify-write statements it compiles to one load / wait / store round trip each.
 template <int SLOTS>
-__device__ bool ldlt_factor(double *M, int N, int lane) {
+__device__ bool ldlt_factor(double *M, int N, int lane, const double tiny) {
+  constexpr int U = 4;
   bool bad_any = false;
+  int row[SLOTS];
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) row[t] = lane + kWave * t;
   for (int k = 0; k < N; ++k) {
     const int ck = col_base(k, N);
-    const double d = M[ck + k];
+    const int tk = k >> 6, lk = k & (kWave - 1);          // owner slot / lane of row k
+    double a[SLOTS];                                       // column k, rows >= k, unscaled
+    double dsel = 0.0;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      a[t] = (row[t] >= k && row[t] < N) ? M[ck + row[t]] : 0.0;
+      dsel = (t == tk) ? a[t] : dsel;
+    }
+    const double d = lane_bcast(dsel, lk);
     const bool bad = !(fabs(d) > 0.0) || !(fabs(d) <= DBL_MAX);
-    bad_any |= bad;
+    bad_any |= bad || !(fabs(d) > tiny);
     double l[SLOTS];
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) {
-      const int i = k + 1 + lane + kWave * t;
-      const double a = (i < N) ? M[ck + i] : 0.0;
-      l[t] = bad ? a : a / d;  // Eigen: A21 /= pivot only when the pivot is non-zero
+      const double v = (row[t] > k) ? a[t] : 0.0;
+      l[t] = bad ? v : v / d;                              // Eigen: A21 /= pivot only when the pivot is non-zero
     }
-#pragma unroll 4
-    for (int j = k + 1; j < N; ++j) {
-      const double c = M[ck + j];  // a_jk before scaling: same address in every lane (broadcast)
-      const int cj = col_base(j, N);
+    // trailing update: M[i][j] -= l_i a_jk for k < j <= i, column by column, U columns per group
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int i = k + 1 + lane + kWave * t;
-        if (i >= j && i < N) M[cj + i] -= l[t] * c;
+    for (int tj = 0; tj < SLOTS; ++tj) {
+      const int jbase = kWave * tj;
+      if (jbase + kWave - 1 > k && jbase < N) {            // wave-uniform: this slot holds columns > k
+        const int jl0 = (k + 1 > jbase) ? k + 1 - jbase : 0;
+        const int jl1 = (N - jbase < kWave) ? N - jbase : kWave;
+        for (int jl = jl0; jl < jl1; jl += U) {
+          double c[U], v[U][SLOTS];
+          int cj[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int jlu = (jl + u < jl1) ? jl + u : jl1 - 1;         // tail: repeat the last column ...
+            c[u] = (jl + u < jl1) ? lane_bcast(a[tj], jlu) : 0.0;      // ... with a zero multiplier
+            cj[u] = col_base(jbase + jlu, N);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int j = jbase + ((jl + u < jl1) ? jl + u : jl1 - 1);
+#pragma unroll
+            for (int t2 = tj; t2 < SLOTS; ++t2) v[u][t2] = (row[t2] >= j && row[t2] < N) ? M[cj[u] + row[t2]] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t2 = tj; t2 < SLOTS; ++t2) v[u][t2] -= l[t2] * c[u];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int j = jbase + jl + u;
+            if (jl + u < jl1) {
+#pragma unroll
+              for (int t2 = tj; t2 < SLOTS; ++t2)
+                if (row[t2] >= j && row[t2] < N) M[cj[u] + row[t2]] = v[u][t2];
+            }
+          }
+        }
       }
     }
-    wave_sync();
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
-      const int i = k + 1 + lane + kWave * t;
-      if (i < N) M[ck + i] = l[t];
-    }
-    wave_sync();
+    for (int t = 0; t < SLOTS; ++t)
+      if (row[t] > k && row[t] < N) M[ck + row[t]] = l[t];
   }
   return bad_any;
 }
@@ -1063,7 +1135,7 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       continue;
     }
     if (cmd == kCmdFactor) {
-      const bool bad = ldlt_factor_share<SLOTS>(M, N, lane, wave, WAVES, ctrl + 2);
+      const bool bad = ldlt_factor_share<SLOTS>(M, N, lane, wave, WAVES, ctrl + 2, (double)ctrl[1]);
       if (lane == 0) ctrl[3 + wave] = bad ? 1.0 : 0.0;
       __syncthreads();                                 // B: factorisation complete
       continue;
@@ -1127,9 +1199,9 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     vtail[t] = (i >= n && i < N) ? beq[i - n] : 0.0;
     is_cone[t] = (i >= s0 && i < s0 + nc);
     if (i < n) all_inf = all_inf && isinf(vlb[t]) && isinf(vub[t]);  // fcc_qp.cpp:132-133
-    if (x0_given) {
+    if (x0_given && !a.warm_start) {
       x[t] = (i < n) ? xs[i] : 0.0; mux[t] = 0.0; mulc[t] = 0.0;
-    } else if (a.warm_start) {                                     // :136-139
+    } else if (a.warm_start) {                                     // :136-139 (x0_given: x is the COD x0)
       x[t] = (i < n) ? xs[i] : 0.0;
       mux[t] = (i < n) ? mux_s[i] : 0.0;
       mulc[t] = is_cone[t] ? mulc_s[i - s0] : 0.0;
@@ -1154,17 +1226,18 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     } else {
       assemble_share<TIN>(M, Q, A, n, N, rho, lane, 0, 1);
       wave_sync();
+      if constexpr (!MAT_IN_LDS) global_phase_sync();
     }
   };
 
   // LDL^T of M in place; with four waves the panels are dealt round-robin (ldlt_factor_share)
-  auto factor = [&]() -> bool {
+  auto factor = [&](const double tiny) -> bool {
     constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
     if constexpr (WAVES > 1) {
       volatile lds_f64 *ctrl = ctrl_word(lds, N, nc);
-      if (lane == 0) { ctrl[0] = (double)kCmdFactor; ctrl[2] = 0.0; }
+      if (lane == 0) { ctrl[0] = (double)kCmdFactor; ctrl[1] = tiny; ctrl[2] = 0.0; }
       __syncthreads();                                 // A
-      const bool mine = ldlt_factor_share<SLOTS>(M, N, lane, 0, WAVES, ctrl + 2);
+      const bool mine = ldlt_factor_share<SLOTS>(M, N, lane, 0, WAVES, ctrl + 2, tiny);
       if (lane == 0) ctrl[3] = mine ? 1.0 : 0.0;
       __syncthreads();                                 // B
       bool bad = false;
@@ -1172,7 +1245,9 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
       for (int w = 0; w < WAVES; ++w) bad = bad || (ctrl[3 + w] != 0.0);
       return bad;
     } else {
-      return ldlt_factor<SLOTS>(M, N, lane);
+      const bool bad = ldlt_factor<SLOTS>(M, N, lane, tiny);
+      if constexpr (!MAT_IN_LDS) global_phase_sync();
+      return bad;
     }
   };
 
@@ -1181,9 +1256,18 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     flags |= kFlagPresolveRan | kFlagPresolveNumerical | kFlagPresolveCod;
   } else if (equality_constrained || !a.warm_start) {
     flags |= kFlagPresolveRan;
+    // breakdown threshold of the unpivoted presolve (see ldlt_panel): N eps max_i |Q_ii|
+    double qmax = 0.0;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const int i = lane + kWave * t;
+      const double q = (i < n) ? fabs((double)Q[(size_t)i * n + i]) : 0.0;
+      qmax = (qmax < q) ? q : qmax;
+    }
+    const double tiny = (double)N * DBL_EPSILON * wave_max(qmax);
     assemble(0.0);
     const long long t0 = wall_clock64();
-    const bool bad = factor();
+    const bool bad = factor(tiny);
     ticks += wall_clock64() - t0;
     if (bad) {
       flags |= kFlagPresolveNumerical;
@@ -1218,7 +1302,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   if (!equality_constrained) {
     assemble(a.rho);                                   // :62-64
     const long long t0 = wall_clock64();
-    const bool bad = factor();                         // :68 (info() unchecked in the reference)
+    const bool bad = factor(0.0);                      // :68 (info() unchecked in the reference)
     ticks += wall_clock64() - t0;
     if (bad) flags |= kFlagAdmmNumerical;
 

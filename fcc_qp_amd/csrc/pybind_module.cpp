@@ -287,4 +287,5 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
   m.attr("FLAG_PRESOLVE_NUMERICAL") = (int)FCCQP_FLAG_PRESOLVE_NUMERICAL;
   m.attr("FLAG_ADMM_NUMERICAL") = (int)FCCQP_FLAG_ADMM_NUMERICAL;
   m.attr("FLAG_EQUALITY_ONLY") = (int)FCCQP_FLAG_EQUALITY_ONLY;
+  m.attr("FLAG_PRESOLVE_COD") = (int)FCCQP_FLAG_PRESOLVE_COD;
 }

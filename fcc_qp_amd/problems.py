@@ -209,6 +209,12 @@ def workload(name: str, batch: int, shape: Shape = WALKING, seed0: int = 1000,
                at iteration 0 (ADMM at rho = 5e-5 is bimodal: an instance either starts feasible or
                runs to max_iter -- the floor-plus-spikes shape of fccqp.pdf Fig. 1).
 
+    ``W-psd``  W-sat with NO cost on the constraint forces (``lambda_reg = 0``): Q is only positive
+               semi-definite, with exact zeros on its diagonal.  K stays non-singular, but the
+               reference's diagonally pivoted LDLT fails on it and its presolve takes the COD branch
+               (fcc_qp.cpp:164-166) -- the likely situation for a logged OSC QP whose cost has no
+               force regularisation (hard part 6).
+
     ``distinct`` caps the number of distinct generated instances; the batch is then tiled from
     them into *separate* buffers (no dedup on the device) -- generation costs ~1 ms/instance.
     """
@@ -220,6 +226,8 @@ def workload(name: str, batch: int, shape: Shape = WALKING, seed0: int = 1000,
             qps.append(osc_qp(seed, shape, activity=4.0))
         elif name == "W-easy":
             qps.append(osc_qp(seed, shape, activity=0.0, ulim=(400.0, 600.0), lambda_reg=1e-2))
+        elif name == "W-psd":
+            qps.append(osc_qp(seed, shape, activity=4.0, lambda_reg=0.0))
         elif name == "W-mix":
             if i % 2 == 0:
                 qps.append(osc_qp(seed, shape, activity=0.0, ulim=(400.0, 600.0), lambda_reg=1e-2))

@@ -9,7 +9,7 @@ import re
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "fcc_qp_amd", "libfccqp_hip.so")
+LIB_PATH = os.environ.get("FCCQP_LIB_PATH") or os.path.join(ROOT, "fcc_qp_amd", "libfccqp_hip.so")   # override: debug builds
 HEADER = os.path.join(ROOT, "include", "fccqp.h")
 
 OK, ERR_INVALID_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_FRICTION, ERR_NOT_SOLVED, ERR_UNSUPPORTED = range(9)

@@ -2,10 +2,13 @@
 
 The reference's Eigen LDLT pivots by the largest remaining diagonal entry and performs two
 triangular solves per ADMM iteration (/root/reference/src/fcc_qp.cpp:68,86).  The HIP kernels use
-(1) an unpivoted LDL^T in natural order and (2) x = x_c + (rho G) w with
-G = (K_rho^-1)[0:n,0:n] built once from that factorisation.  This test restates (1)+(2) in numpy
-and compares against the oracle (Eigen's order): agreement is at rounding level, far inside the
-stated 1e-6 parity tolerance -- the evidence behind the kernel design, runnable without a GPU."""
+(1) an unpivoted LDL^T in natural order, (2) x = x_c + (rho G) w with
+G = (K_rho^-1)[0:n,0:n] built once from that factorisation, and -- the fused kernel -- (3) the
+presolve x0 = (K^-1 [-b; b_eq]).head(n) (fcc_qp.cpp:159-178) as x0 = (I - rho G)^-1 x_c (Woodbury
+on K = K_rho - rho E E^T), i.e. without ever factorising K.  This test restates (1)+(2)+(3) in
+numpy and compares against the oracle (Eigen's order, its own presolve, its COD where its LDLT
+fails): agreement is at rounding level, far inside the stated 1e-6 parity tolerance -- the evidence
+behind the kernel design, runnable without a GPU."""
 import numpy as np
 import scipy.linalg as sl
 
@@ -30,19 +33,25 @@ def ldl_solve(L, D, r):
     return sl.solve_triangular(L.T, y, lower=False, unit_diagonal=True)
 
 
-def kernel_algorithm(qp, opts, dims):
+def kernel_algorithm(qp, opts, dims, woodbury=True):
     n, m, nc, s = dims
     Q, A, b, beq = qp["Q"], qp["A_eq"], qp["b"], qp["b_eq"]
     lb, ub, mus, rho = qp["lb"], qp["ub"], qp["friction_coeffs"], opts["rho"]
     K = np.zeros((n + m, n + m)); K[:n, :n] = Q; K[n:, :n] = A; K[:n, n:] = A.T
     rhs = np.r_[-b, beq]
-    L0, D0 = ldl_natural(K)
-    x = ldl_solve(L0, D0, rhs)[:n]                                   # presolve
     Kr = K.copy(); Kr[:n, :n] += rho * np.eye(n)
     L, D = ldl_natural(Kr)
     E = np.zeros((n + m, n)); E[:n] = np.eye(n)
     M = rho * ldl_solve(L, D, E)[:n]                                 # rho * G
     xc = ldl_solve(L, D, rhs)[:n]
+    if woodbury:                                                     # fused kernel: x0 = (I - rho G)^-1 x_c
+        W = np.tril(np.eye(n) - M); W = W + np.tril(W, -1).T         # the kernel reads the lower triangle
+        Lw, Dw = ldl_natural(W)
+        assert Dw.min() > 1e-10                                      # kPresolveMinPivot
+        x = ldl_solve(Lw, Dw, xc)
+    else:                                                            # generic kernel: direct LDL^T of K
+        L0, D0 = ldl_natural(K)
+        x = ldl_solve(L0, D0, rhs)[:n]
     xbar = x.copy(); lcbar = x[s:s + nc].copy(); mux = np.zeros(n); mul = np.zeros(nc)
     nit = opts["max_iter"]
     for it in range(opts["max_iter"]):
@@ -67,8 +76,25 @@ def test_natural_order_and_explicit_g_match_the_reference_order(oracle):
         B = P.workload(wl, 6, P.WALKING)
         z_ref, it_ref, _, _ = oracle.solve_batch(dims, opts, *B.arrays(), nthreads=2)
         for i in range(B.batch):
-            z, nit = kernel_algorithm(B.instance(i), opts, dims)
-            err = np.max(np.abs(z - z_ref[i])) / (1 + np.max(np.abs(z_ref[i])))
-            worst = max(worst, err)
-            assert nit == it_ref[i]
+            for wb in (True, False):
+                z, nit = kernel_algorithm(B.instance(i), opts, dims, woodbury=wb)
+                err = np.max(np.abs(z - z_ref[i])) / (1 + np.max(np.abs(z_ref[i])))
+                worst = max(worst, err)
+                assert nit == it_ref[i]
     assert worst < 1e-10, worst          # observed ~4e-13
+
+
+def test_woodbury_presolve_on_semidefinite_costs(oracle):
+    """W-psd: no cost on the constraint forces (exact zeros on the diagonal of Q).  The reference's
+    LDLT fails on K and it takes its COD (the oracle reports presolve_ldlt_info = 1); an unpivoted
+    LDL^T of K breaks down outright (zero pivot); the Woodbury presolve needs neither."""
+    dims = P.WALKING.ctor_args
+    B = P.workload("W-psd", 6, P.WALKING)
+    for opts in (P.HARNESS_OPTIONS, dict(max_iter=50, rho=1e-2, eps_fcone=1e-6, eps_bound=1e-6),
+                 dict(max_iter=0, rho=1e-6, eps_fcone=1e-6, eps_bound=1e-6)):      # max_iter 0: z = x0
+        z_ref, it_ref, det, _ = oracle.solve_batch(dims, opts, *B.arrays(), nthreads=2)
+        for i in range(B.batch):
+            assert det[i].presolve_ldlt_info == 1
+            z, nit = kernel_algorithm(B.instance(i), opts, dims, woodbury=True)
+            assert nit == it_ref[i]
+            assert np.max(np.abs(z - z_ref[i])) <= 1e-9 * (1 + np.max(np.abs(z_ref[i])))

@@ -1104,6 +1104,20 @@ __device__ __forceinline__ void g_build_mfma_single(lds_f64 *M, const int N, con
   }
 }
 
+// ---- presolve out of the K_rho factorisation ------------------------------------------------------------
+// x0 = (K^-1 [-b; b_eq]).head(n) = (I - rho G)^-1 x_c  (Woodbury on K = K_rho - rho E E^T; derivation and
+// accuracy in fccqp_fused_impl.h, "presolve").  W = I - rho G is symmetric positive definite exactly when
+// K is non-singular, with eigenvalues in (0, 1]; a pivot <= kPresolveMinPivot sends the instance to the
+// COD fallback.  This wave's share of W, packed lower, from the staged rho G (column-major, global):
+constexpr double kPresolveMinPivot = 1e-10;
+__device__ __forceinline__ void presolve_w_share(lds_f64 *M, const double *stage, const int n, const int lane,
+                                                 const int part, const int parts) {
+  for (int j = part; j < n; j += parts) {
+    const int cj = col_base(j, n);
+    for (int i = j + lane; i < n; i += kWave) M[cj + i] = ((i == j) ? 1.0 : 0.0) - stage[(size_t)j * n + i];
+  }
+}
+
 // waves 1..WAVES-1 of a multi-wave workgroup, for one instance
 template <int SLOTS, int WAVES, class TIN, class SHP>
 __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, const int wave, const int lane) {
@@ -1150,6 +1164,10 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();                                   // B: every column of G is staged, L is dead
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if ((double)ctrl[1] != 0.0) {                      // the solver wave wants x0 out of G first:
+      __syncthreads();                                 // B2: ... it builds W = I - rho G in LDS,
+      __syncthreads();                                 // B3: factorises it and solves for x0
+    }
     const int total = n * n;
 #pragma unroll 8
     for (int e = wave * kWave + lane; e < total; e += WAVES * kWave) M[e] = stage[e];
@@ -1251,47 +1269,80 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     }
   };
 
+  // Can this instance run on the explicit operator x = x_c + (rho G) w (see the ADMM loop)?  Everything
+  // but the iteration-count condition; needed here because G also yields the presolve.
+  constexpr int GS = (SLOTS < 2) ? SLOTS : 2;        // register slots that hold variables (n <= 128)
+  constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
+  bool single_mfma = false;
+  if constexpr (MAT_IN_LDS && WAVES == 1)
+    single_mfma = a.workspace != nullptr && g_build_mfma_single_supported(N, n, a.workspace_stride);
+  const int gswitch = (WAVES > 1 || single_mfma) ? kGSwitchIterMulti : kGSwitchIter;
+  const int w_off = g_w_off(n), w_len = g_w_len(n);
+  bool g_possible = false;
+  if constexpr (MAT_IN_LDS && SLOTS <= 4) {
+    g_possible = a.workspace != nullptr && n <= 2 * kWave && n > 0 && w_off + w_len <= npack &&
+                 a.workspace_stride >= (long long)n * n;
+  }
+  bool use_g = g_possible &&
+               a.max_iter - gswitch >= ((WAVES > 1 || single_mfma) ? kGMinRemainingMulti : kGMinRemaining);
+
   // ---- presolve (fcc_qp.cpp:159-178): skipped on warm start unless equality-only ---------
+  // Three ways to x0 = (K^-1 [-b; b_eq]).head(n):
+  //  (w) out of the K_rho factorisation, x0 = (I - rho G)^-1 x_c, when G is going to be built anyway
+  //      (use_g): no factorisation of K, no second assembly -- and no breakdown on semi-definite costs;
+  //  (d) the direct unpivoted LDL^T of K, as the reference does with its pivoted one: equality-only
+  //      instances (no K_rho at all), shapes / iteration limits without G;
+  //  (c) the COD fallback pass, where (d) breaks down and (w) is not possible, or W is singular.
+  bool need_w = false;
   if (x0_given) {
     flags |= kFlagPresolveRan | kFlagPresolveNumerical | kFlagPresolveCod;
   } else if (equality_constrained || !a.warm_start) {
     flags |= kFlagPresolveRan;
-    // breakdown threshold of the unpivoted presolve (see ldlt_panel): N eps max_i |Q_ii|
-    double qmax = 0.0;
+    if (!equality_constrained && use_g) {
+      need_w = true;                                   // (w)
+    } else {
+      // breakdown threshold of the unpivoted presolve (see ldlt_panel): 16 N eps max_i |Q_ii|
+      double qmax = 0.0;
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
-      const int i = lane + kWave * t;
-      const double q = (i < n) ? fabs((double)Q[(size_t)i * n + i]) : 0.0;
-      qmax = (qmax < q) ? q : qmax;
-    }
-    const double tiny = (double)N * DBL_EPSILON * wave_max(qmax);
-    assemble(0.0);
-    const long long t0 = wall_clock64();
-    const bool bad = factor(tiny);
-    ticks += wall_clock64() - t0;
-    if (bad) {
-      flags |= kFlagPresolveNumerical;
-      if (a.fb_list) {
-        // where the reference switches to its COD fallback (fcc_qp.cpp:164-166): hand the
-        // instance to the fallback pass and stop here
-        if (lane == 0) {
-          a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
-          a.flags[inst] = flags;
-        }
-        return;
+      for (int t = 0; t < SLOTS; ++t) {
+        const int i = lane + kWave * t;
+        const double q = (i < n) ? fabs((double)Q[(size_t)i * n + i]) : 0.0;
+        qmax = (qmax < q) ? q : qmax;
       }
-    }
-    double r[SLOTS];
+      const double tiny = 16.0 * (double)N * DBL_EPSILON * wave_max(qmax);
+      assemble(0.0);
+      const long long t0 = wall_clock64();
+      const bool bad = factor(tiny);
+      ticks += wall_clock64() - t0;
+      if (bad && !equality_constrained && g_possible) {
+        need_w = true;                                 // (d) broke down: (w) after all
+        use_g = true;
+      } else if (bad) {
+        flags |= kFlagPresolveNumerical;
+        if (a.fb_list) {
+          // where the reference switches to its COD fallback (fcc_qp.cpp:164-166): hand the
+          // instance to the fallback pass and stop here
+          if (lane == 0) {
+            a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
+            a.flags[inst] = flags;
+          }
+          return;
+        }
+      }
+      if (!need_w) {
+        double r[SLOTS];
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
-      const int i = lane + kWave * t;
-      r[t] = (i < n) ? -vb[t] : vtail[t];  // [-b; b_eq]  (:149-150)
-    }
-    ldlt_solve<SLOTS, MP>(M, N, lane, r);
+        for (int t = 0; t < SLOTS; ++t) {
+          const int i = lane + kWave * t;
+          r[t] = (i < n) ? -vb[t] : vtail[t];  // [-b; b_eq]  (:149-150)
+        }
+        ldlt_solve<SLOTS, MP>(M, N, lane, r);
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
-      const int i = lane + kWave * t;
-      x[t] = (i < n) ? r[t] : 0.0;       // x_ = sol.head(n)  (:174)
+        for (int t = 0; t < SLOTS; ++t) {
+          const int i = lane + kWave * t;
+          x[t] = (i < n) ? r[t] : 0.0;       // x_ = sol.head(n)  (:174)
+        }
+      }
     }
   }
 
@@ -1329,30 +1380,22 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     // copied into LDS over L, which is not needed any more: an iteration becomes an n x n mat-vec
     // (~15x fewer instructions than the sweeps at N = 174).  Building G costs about 30 sweep
     // iterations, so it is only done for instances that have already shown they iterate.
-    constexpr int GS = (SLOTS < 2) ? SLOTS : 2;        // register slots that hold variables (n <= 128)
+    // A cold instance that takes its presolve from G (need_w, see above) builds G before the first
+    // iteration instead -- the pass iter == -1 of the loop below -- and iterates on the operator
+    // from the start.
     constexpr int RB = g_batch<SLOTS>();
-    constexpr int WAVES = waves_for<SLOTS, MAT_IN_LDS>();
-    bool single_mfma = false;
-    if constexpr (MAT_IN_LDS && WAVES == 1)
-      single_mfma = a.workspace != nullptr && g_build_mfma_single_supported(N, n, a.workspace_stride);
-    const int gswitch = (WAVES > 1 || single_mfma) ? kGSwitchIterMulti : kGSwitchIter;
     // LDS doubles after the switch: rho*G [n][n] (column-major) | w [w_len], zero-padded | partial sums
-    const int g_off = 0, w_off = g_w_off(n), w_len = g_w_len(n);
-    bool use_g = false, g_ready = false;
-    if constexpr (MAT_IN_LDS && SLOTS <= 4) {
-      use_g = a.workspace != nullptr && n <= 2 * kWave && n > 0 && w_off + w_len <= npack &&
-              a.workspace_stride >= (long long)n * n &&
-              a.max_iter - gswitch >= ((WAVES > 1 || single_mfma) ? kGMinRemainingMulti : kGMinRemaining);
-    }
+    const int g_off = 0;
+    bool g_ready = false;
     const bool coop_mv = (WAVES > 1) && g_part_off(n) + WAVES * 2 * kWave <= npack;
     double xc[GS];
 #pragma unroll
     for (int t = 0; t < GS; ++t) xc[t] = 0.0;
 
     n_iter = a.max_iter;                               // :78
-    for (int iter = 0; iter < a.max_iter; ++iter) {
+    for (int iter = need_w ? -1 : 0; iter < a.max_iter; ++iter) {
       if constexpr (MAT_IN_LDS && SLOTS <= 4) {
-        if (use_g && iter == gswitch) {
+        if (use_g && !g_ready && (iter == gswitch || iter < 0)) {
           double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
           if constexpr (WAVES > 1) {
             if (g_build_mfma_supported(N, n)) {        // [-b; b_eq] where every wave can read it
@@ -1363,7 +1406,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
                 if (i < N) rhs_s[i] = (i < n) ? -vb[t] : vtail[t];
               }
             }
-            if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdBuild;
+            if (lane == 0) { ctrl_word(lds, N, nc)[0] = (double)kCmdBuild; ctrl_word(lds, N, nc)[1] = (iter < 0) ? 1.0 : 0.0; }
             __syncthreads();                           // A (see helper_wave)
           }
           bool by_mfma = false;
@@ -1415,14 +1458,53 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               }
             }
           }
+          bool wbad = false;
+          if (iter < 0) {
+            // presolve: x0 = (I - rho G)^-1 x_c.  W goes over the dead factor in LDS (all waves), this
+            // wave factorises it (n x n, one-wave panel code) and solves; G itself is copied in after.
+            // (this wave alone: 4 us at n = 114.  With the helpers sharing the columns, the four-slot
+            // kernel -- and only that instantiation -- hung or faulted in their copy of the loop;
+            // their code is left exactly as it is without the presolve)
+            presolve_w_share(M, stage, n, lane, 0, 1);
+            if constexpr (WAVES > 1) __syncthreads();  // B2
+            else wave_sync();
+            const long long tw = wall_clock64();
+            wbad = ldlt_factor<GS>(M, n, lane, kPresolveMinPivot);
+            ticks += wall_clock64() - tw;
+            double xw[GS];
+#pragma unroll
+            for (int t = 0; t < GS; ++t) xw[t] = xc[t];
+            ldlt_solve<GS, lds_f64 *>(M, n, lane, xw);
+#pragma unroll
+            for (int t = 0; t < SLOTS; ++t) {
+              x[t] = 0.0;
+              if (t < GS) x[t] = (lane + kWave * t < n) ? xw[t < GS ? t : 0] : 0.0;
+              xbar[t] = x[t]; lcbar[t] = x[t];           // :74-75
+            }
+            if constexpr (WAVES > 1) __syncthreads();  // B3
+            else wave_sync();
+          }
           const int total = n * n;
 #pragma unroll 8
           for (int e = lane; e < total; e += WAVES * kWave) M[g_off + e] = stage[e];
           if constexpr (WAVES > 1) __syncthreads();    // C
           else wave_sync();
           g_ready = true;
+          if (wbad) {
+            // W singular to working precision: K is singular; the reference's COD gives the
+            // minimum-norm solution (fcc_qp.cpp:164-166,176) -> fallback pass
+            flags |= kFlagPresolveNumerical;
+            if (a.fb_list) {
+              if (lane == 0) {
+                a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
+                a.flags[inst] = flags;
+              }
+              return;
+            }
+          }
         }
       }
+      if (iter < 0) continue;
       if (g_ready) {
         if constexpr (MAT_IN_LDS && SLOTS <= 4) {
           lds_f64 *wbuf = M + w_off;

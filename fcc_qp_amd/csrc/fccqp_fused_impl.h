@@ -715,6 +715,19 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
   }
 }
 
+// acc[j % 4] += Wq[j / 16](lane j % 16 of this lane's 16-lane row) * Mrow[j], j = J .. NN-1: the mat-vec of
+// an ADMM iteration with the vector operand fetched by the FMA itself (DPP row_newbcast); four
+// accumulators break the FMA dependency chain.  (A recursive template, not a lambda: clang does not
+// capture variables that a generic lambda only names in asm operands.)
+template <int J, int NN, int NQ>
+__device__ __forceinline__ void dpp_matvec(double (&acc)[4], const double (&Wq)[NQ], const double (&Mrow)[NN]) {
+  if constexpr (J < NN) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc[J % 4]) : "v"(Wq[J / 16]), "v"(Mrow[J]), "n"(J % 16));
+    dpp_matvec<J + 1, NN, NQ>(acc, Wq, Mrow);
+  }
+}
+
 // TIN: storage type of Q and A_eq (double, or float for the fp32-storage entry points: widened on
 // load).  A template parameter rather than a run-time flag: an extra code path in the assembly
 // phase perturbed the register allocation of the whole kernel (36 VGPR spills, +30% on the ADMM
@@ -934,45 +947,28 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       const double w = (cone_i != 0) ? (lcbar - mulc) : (xbar - mux);
       vbuf[lane] = (var_i != 0) ? w : 0.0;
       lds_fence();
-      // x = x_c + (rho G) w   == the KKT solve of :83-87.  w comes back from LDS as broadcast pairs,
-      // in chunks of 7 pairs with two chunks in flight (<= 15 loads: the lgkmcnt counter has 4 bits): a lone wave per SIMD has nobody to hide
-      // the ~100-cycle LDS latency behind, so the loads must run ahead of the FMAs (left to itself
-      // the compiler kept 2 loads in flight and stalled on every one).
-      double acc0 = xc, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-      {
-        const lds_d2 *w2 = reinterpret_cast<const lds_d2 *>(vbuf);
-        constexpr int NP = (n + 1) / 2, CH = 7, NCHUNK = (NP + CH - 1) / CH;
-        d2 wb[2][CH];
-        auto load = [&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          static_for<0, CH>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            if constexpr (c * CH + i < NP) wb[c % 2][i] = w2[c * CH + i];
-          });
-        };
-        load(std::integral_constant<int, 0>{});
-        static_for<0, NCHUNK>([&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          if constexpr (c + 1 < NCHUNK) load(std::integral_constant<int, c + 1>{});
-          __builtin_amdgcn_sched_barrier(0);
-          // one wait per chunk instead of one per FMA pair (each s_waitcnt is an issue slot)
-          constexpr int nxt = (c + 1 < NCHUNK) ? (((c + 2) * CH <= NP) ? CH : NP - (c + 1) * CH) : 0;
-          __builtin_amdgcn_s_waitcnt(0xC07F | (nxt << 8));
-          static_for<0, CH>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int j = 2 * (c * CH + i);
-            if constexpr (j < n) {
-              if constexpr (i % 2 == 0) acc0 = fma(Mrow[j], wb[c % 2][i].x, acc0);
-              else acc2 = fma(Mrow[j], wb[c % 2][i].x, acc2);
-            }
-            if constexpr (j + 1 < n) {
-              if constexpr (i % 2 == 0) acc1 = fma(Mrow[j + 1], wb[c % 2][i].y, acc1);
-              else acc3 = fma(Mrow[j + 1], wb[c % 2][i].y, acc3);
-            }
-          });
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
+      // x = x_c + (rho G) w   == the KKT solve of :83-87, lane i = row i of rho G.  Every lane needs all
+      // of w.  Reading it back as LDS broadcasts (ds_read_b128 of two doubles into all 64 lanes: a
+      // 1-KiB return per instruction) made the four waves of a CU wait on the LDS return path: 409 ns
+      // per mat-vec.  Instead each 16-lane row takes a copy of w, 16 entries per register
+      // (Wq[lane] = w[16 q + (lane & 15)]: NQ plain ds_read_b64), and the FMA itself fetches its
+      // operand from lane l of the row (v_fmac_f64 with the DPP control row_newbcast:l, the one DPP
+      // mode the fp64 ALU has): no LDS traffic, no extra instruction -- 216 ns against the 136 ns floor
+      // of 60 FMAs with register operands (tools/dpp_bench.hip).
+      constexpr int NQ = (n + 15) / 16;
+      double Wq[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];   // entries >= n were written as 0
+      lds_fence();
+      double acc[4] = {xc, 0.0, 0.0, 0.0};
+      // the DPP read of a VGPR needs two wait states after a VALU write of it (the registers come
+      // straight from the LDS reads, but a copy could be scheduled in between): pin them here
+      if constexpr (NQ == 4) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]), "+v"(Wq[3]));
+      else if constexpr (NQ == 3) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]));
+      else if constexpr (NQ == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
+      else asm volatile("s_nop 1" : "+v"(Wq[0]));
+      dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
+      const double acc0 = acc[0], acc1 = acc[1], acc2 = acc[2], acc3 = acc[3];
       x = (acc0 + acc1) + (acc2 + acc3);
       lds_fence();
       // slack update :90-92

@@ -1298,7 +1298,10 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     flags |= kFlagPresolveRan | kFlagPresolveNumerical | kFlagPresolveCod;
   } else if (equality_constrained || !a.warm_start) {
     flags |= kFlagPresolveRan;
-    if (!equality_constrained && use_g) {
+    // (w) first only in one-wave workgroups: with four waves the K factorisation is shared by the
+    // waves (72 us at N = 174) while W is factorised by this wave alone (70 us at n = 114) -- measured
+    // 438 k vs 453 k solves/s on the large shape; there (w) is the second chance after (d)
+    if (!equality_constrained && use_g && WAVES == 1) {
       need_w = true;                                   // (w)
     } else {
       // breakdown threshold of the unpivoted presolve (see ldlt_panel): 16 N eps max_i |Q_ii|

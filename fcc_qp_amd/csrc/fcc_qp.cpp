@@ -3,6 +3,8 @@
 // delegated to the HIP library.  Plain C++17, no HIP headers: this file only sees the C ABI.
 #include "fcc_qp.hpp"
 
+#include <thread>
+
 #include <cmath>
 #include <string>
 
@@ -209,6 +211,91 @@ long long FCCQPBatch::AlgorithmicBytes() const {
   long long b = 0;
   check(fccqp_algorithmic_bytes(h_, &b), h_, "FCCQPBatch::AlgorithmicBytes");
   return b;
+}
+
+// ---------------------------------------------------------------------------- FCCQPSharded
+FCCQPSharded::FCCQPSharded(int num_vars, int num_equality_constraints, int nc, int lambda_c_start,
+                           int batch, const std::vector<int> &devices)
+    : n_vars_(num_vars), n_eq_(num_equality_constraints), nc_(nc), lambda_c_start_(lambda_c_start),
+      batch_(batch), devices_(devices) {
+  if (devices.empty()) throw FccqpError(FCCQP_ERR_INVALID_ARG, "FCCQPSharded: empty device list");
+  if (batch < (int)devices.size()) throw FccqpError(FCCQP_ERR_SHAPE, "FCCQPSharded: fewer instances than shards");
+  h_.assign(devices.size(), nullptr);
+  for (size_t g = 0; g < devices.size(); ++g) {
+    const int nb = shard_begin((int)g + 1) - shard_begin((int)g);
+    int rc = fccqp_create(num_vars, num_equality_constraints, nc, lambda_c_start, nb, devices[g], &h_[g]);
+    if (rc != FCCQP_OK) {
+      for (auto *h : h_) fccqp_destroy(h);
+      check(rc, nullptr, "FCCQPSharded::FCCQPSharded");
+    }
+  }
+}
+FCCQPSharded::~FCCQPSharded() {
+  for (auto *h : h_) fccqp_destroy(h);
+}
+void FCCQPSharded::set_options(FCCQPOptions opt) {
+  options_ = opt;
+  fccqp_options o = to_c(options_);
+  for (auto *h : h_) check(fccqp_set_options(h, &o), h, "FCCQPSharded::set_options");
+}
+void FCCQPSharded::set_warm_start(bool warm_start) {
+  for (auto *h : h_) check(fccqp_set_warm_start(h, warm_start ? 1 : 0), h, "FCCQPSharded::set_warm_start");
+}
+void FCCQPSharded::set_kernel(int kernel) {
+  for (auto *h : h_) check(fccqp_set_kernel(h, kernel), h, "FCCQPSharded::set_kernel");
+}
+
+void FCCQPSharded::Solve(const double *Q, const double *b, const double *A_eq, const double *b_eq,
+                         const double *friction_coeffs, int n_friction, const double *lb,
+                         const double *ub) {
+  const size_t n = (size_t)n_vars_, m = (size_t)n_eq_, G = h_.size();
+  std::vector<int> rc(G, FCCQP_OK);
+  std::vector<std::thread> th;
+  th.reserve(G);
+  for (size_t g = 0; g < G; ++g) {
+    th.emplace_back([&, g] {
+      const size_t lo = (size_t)shard_begin((int)g);
+      rc[g] = fccqp_solve(h_[g], Q + lo * n * n, b + lo * n, A_eq ? A_eq + lo * m * n : nullptr,
+                          b_eq ? b_eq + lo * m : nullptr,
+                          friction_coeffs ? friction_coeffs + lo * (size_t)n_friction : nullptr, n_friction,
+                          lb + lo * n, ub + lo * n);
+    });
+  }
+  for (auto &t : th) t.join();
+  for (size_t g = 0; g < G; ++g) check(rc[g], h_[g], "FCCQPSharded::Solve");
+}
+
+FCCQPBatchSolution FCCQPSharded::GetSolution() const {
+  FCCQPBatchSolution out;
+  out.batch = batch_;
+  out.num_vars = n_vars_;
+  out.z.assign((size_t)batch_ * (size_t)n_vars_, 0.0);
+  std::vector<fccqp_details> d((size_t)batch_);
+  const size_t G = h_.size();
+  std::vector<int> rc(G, FCCQP_OK);
+  std::vector<std::thread> th;
+  th.reserve(G);
+  for (size_t g = 0; g < G; ++g) {
+    th.emplace_back([&, g] {
+      const size_t lo = (size_t)shard_begin((int)g);
+      rc[g] = fccqp_get_solution(h_[g], out.z.data() + lo * (size_t)n_vars_, d.data() + lo);
+    });
+  }
+  for (auto &t : th) t.join();
+  for (size_t g = 0; g < G; ++g) check(rc[g], h_[g], "FCCQPSharded::GetSolution");
+  out.details.reserve((size_t)batch_);
+  for (const auto &x : d) out.details.push_back(from_c(x));
+  return out;
+}
+
+float FCCQPSharded::LastKernelMilliseconds() const {
+  float worst = 0.f;
+  for (auto *h : h_) {
+    float ms = 0.f;
+    check(fccqp_last_kernel_ms(h, &ms), h, "FCCQPSharded::LastKernelMilliseconds");
+    worst = ms > worst ? ms : worst;
+  }
+  return worst;
 }
 
 }  // namespace fcc_qp

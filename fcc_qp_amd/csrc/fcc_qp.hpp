@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+
 struct fccqp_solver;  // include/fccqp.h
 
 namespace fcc_qp {
@@ -169,6 +170,50 @@ class FCCQPBatch {
   FCCQPOptions options_;
   const int n_vars_, n_eq_, nc_, lambda_c_start_, batch_;
   fccqp_solver *h_ = nullptr;
+};
+
+/*!
+ * One instance-major host batch split over several solver handles -- normally one per GPU of the
+ * node: shard g takes the instances [g B / G, (g + 1) B / G) and solves them
+ * on device `devices[g]`, one host thread per shard; results are gathered back into one
+ * instance-major array.  No data-path collective: every QP is independent (all reference state is per
+ * instance, src/fcc_qp.hpp:130-171), so nothing crosses between the devices; the warm-start state
+ * of a shard stays resident on its own device between solves.  The same device may be listed more
+ * than once (the 1-GPU test runs two shards on device 0).
+ */
+class FCCQPSharded {
+ public:
+  FCCQPSharded(int num_vars, int num_equality_constraints, int nc, int lambda_c_start, int batch,
+               const std::vector<int> &devices);
+  ~FCCQPSharded();
+  FCCQPSharded(const FCCQPSharded &) = delete;
+  FCCQPSharded &operator=(const FCCQPSharded &) = delete;
+
+  void set_options(FCCQPOptions opt);
+  void set_warm_start(bool warm_start);
+  void set_kernel(int kernel);
+  FCCQPOptions get_options() const { return options_; }
+
+  // host pointers to the whole batch; n_friction = friction coefficients per instance (>= nc/3)
+  void Solve(const double *Q, const double *b, const double *A_eq, const double *b_eq,
+             const double *friction_coeffs, int n_friction, const double *lb, const double *ub);
+  FCCQPBatchSolution GetSolution() const;
+  // slowest shard's device time for the last Solve (ms)
+  float LastKernelMilliseconds() const;
+
+  int batch() const { return batch_; }
+  int shards() const { return (int)h_.size(); }
+  int shard_begin(int g) const { return (int)(((long long)batch_ * g) / (long long)h_.size()); }
+  int device_of(int g) const { return devices_[(size_t)g]; }
+  int num_vars() const { return n_vars_; }
+  int num_equality_constraints() const { return n_eq_; }
+  int nc() const { return nc_; }
+
+ private:
+  FCCQPOptions options_;
+  const int n_vars_, n_eq_, nc_, lambda_c_start_, batch_;
+  std::vector<int> devices_;
+  std::vector<fccqp_solver *> h_;
 };
 
 }  // namespace fcc_qp

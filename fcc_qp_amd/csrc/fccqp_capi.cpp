@@ -32,7 +32,8 @@ struct fccqp_solver {
   size_t lds_limit = 64 * 1024;
   hipStream_t stream = nullptr;      // the solver's own stream
   hipStream_t last_stream = nullptr; // stream of the last enqueue
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;   // kernel start / end, async result copy
+  bool copy_pending = false;
   // staged inputs (host-pointer solve)
   double *wb = nullptr, *wbeq = nullptr, *wmu = nullptr, *wlb = nullptr, *wub = nullptr;  // widened vectors
   double *dQ = nullptr, *db = nullptr, *dA = nullptr, *dbeq = nullptr, *dmu = nullptr,
@@ -267,6 +268,7 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
     HIP_TRY(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY(s, hipEventCreate(&s->ev0));
     HIP_TRY(s, hipEventCreate(&s->ev1));
+    HIP_TRY(s, hipEventCreateWithFlags(&s->ev2, hipEventDisableTiming));
     const size_t B = (size_t)batch, n = (size_t)num_vars;
     HIP_TRY(s, dmalloc(&s->dx, B * n));
     HIP_TRY(s, dmalloc(&s->dmux, B * n));
@@ -285,7 +287,8 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
     HIP_TRY(s, hipMemset(s->dticks, 0, sizeof(long long) * B));
     s->work_stride = fccqp::generic_workspace_doubles(num_vars, num_equality_constraints, nc, lds);
     if (s->work_stride > 0) HIP_TRY(s, dmalloc(&s->dwork, B * (size_t)s->work_stride));
-    HIP_TRY(s, dmalloc(&s->dfb_list, B));
+    HIP_TRY(s, dmalloc(&s->dfb_list, B + 2));
+    HIP_TRY(s, hipMemset(s->dfb_list, 0, sizeof(int) * (B + 2)));
     HIP_TRY(s, dmalloc(&s->dfb_count, 2));
     HIP_TRY(s, hipMemset(s->dfb_count, 0, 2 * sizeof(int)));
     s->cod_stride = fccqp::cod_workspace_doubles_host(num_vars, num_equality_constraints);
@@ -312,6 +315,7 @@ int fccqp_destroy(fccqp_solver *s) {
     if (p) (void)hipFree(p);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->ev2) (void)hipEventDestroy(s->ev2);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return FCCQP_OK;
@@ -367,9 +371,51 @@ int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc, 
   return FCCQP_OK;
 }
 
+namespace {
+int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
+               const double *b_eq, const double *friction_coeffs, int n_friction,
+               const double *lb, const double *ub, bool wait);
+}
+
 int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
                 const double *b_eq, const double *friction_coeffs, int n_friction,
                 const double *lb, const double *ub) {
+  return solve_host(s, Q, b, A_eq, b_eq, friction_coeffs, n_friction, lb, ub, true);
+}
+
+int fccqp_solve_async(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
+                      const double *b_eq, const double *friction_coeffs, int n_friction,
+                      const double *lb, const double *ub) {
+  if (s && n_friction != (int)n_mu(s)) return fail(s, FCCQP_ERR_FRICTION_COEFFS, "fccqp_solve_async: n_friction must be nc/3");
+  return solve_host(s, Q, b, A_eq, b_eq, friction_coeffs, n_friction, lb, ub, false);
+}
+
+int fccqp_host_register(void *ptr, size_t bytes) {
+  if (!ptr || !bytes) return FCCQP_ERR_INVALID_ARG;
+  return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? FCCQP_OK : FCCQP_ERR_HIP;
+}
+int fccqp_host_unregister(void *ptr) {
+  if (!ptr) return FCCQP_ERR_INVALID_ARG;
+  return hipHostUnregister(ptr) == hipSuccess ? FCCQP_OK : FCCQP_ERR_HIP;
+}
+
+int fccqp_get_z_async(fccqp_solver *s, double *z_pinned) {
+  if (!s || !z_pinned) return FCCQP_ERR_INVALID_ARG;
+  if (!s->solved) return fail(s, FCCQP_ERR_NOT_SOLVED, "GetSolution before Solve");
+  DeviceGuard g(s->device);
+  // behind the last solve, wherever it was enqueued
+  if (s->last_stream != s->stream) HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev1, 0));
+  HIP_TRY(s, hipMemcpyAsync(z_pinned, s->dx, sizeof(double) * (size_t)s->batch * (size_t)s->n,
+                            hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipEventRecord(s->ev2, s->stream));
+  s->copy_pending = true;
+  return FCCQP_OK;
+}
+
+namespace {
+int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
+               const double *b_eq, const double *friction_coeffs, int n_friction,
+               const double *lb, const double *ub, bool wait) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   const size_t B = (size_t)s->batch, n = (size_t)s->n, m = (size_t)s->m, nm = n_mu(s);
   if ((n && (!Q || !b || !lb || !ub)) || (m && n && !A_eq) || (m && !b_eq) || (nm && !friction_coeffs))
@@ -398,11 +444,16 @@ int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double 
   HIP_TRY(s, hipMemcpyAsync(s->dub, ub, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
   rc = enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st);
   if (rc != FCCQP_OK) return rc;
+  if (!wait) {
+    s->last_solve_wall = 0.0;   // reported as the kernel time, like a device-pointer solve
+    return FCCQP_OK;
+  }
   HIP_TRY(s, hipStreamSynchronize(st));
   const auto t1 = std::chrono::high_resolution_clock::now();
   s->last_solve_wall = std::chrono::duration<double>(t1 - t0).count();  // src/fcc_qp.cpp:188-190
   return FCCQP_OK;
 }
+}  // namespace
 
 int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, const double *dA_eq,
                        const double *db_eq, const double *dfriction, const double *dlb,
@@ -478,6 +529,10 @@ int fccqp_synchronize(fccqp_solver *s) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   DeviceGuard g(s->device);
   if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  if (s->copy_pending) {
+    HIP_TRY(s, hipEventSynchronize(s->ev2));
+    s->copy_pending = false;
+  }
   return FCCQP_OK;
 }
 
@@ -584,6 +639,17 @@ int fccqp_phase_seconds(fccqp_solver *s, double out[8]) {
     for (size_t i = 0; i < B; ++i) acc += (double)h[(size_t)p * B + i];
     out[p] = 1e-8 * acc / (double)B;
   }
+  return FCCQP_OK;
+}
+
+int fccqp_debug_read_workspace(fccqp_solver *s, double *out, long long count, long long *available) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  DeviceGuard g(s->device);
+  if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  const long long have = s->dwork ? (long long)s->batch * s->work_stride : 0;
+  if (available) *available = have;
+  const long long take = count < have ? count : have;
+  if (out && take > 0) HIP_TRY(s, hipMemcpy(out, s->dwork, sizeof(double) * (size_t)take, hipMemcpyDeviceToHost));
   return FCCQP_OK;
 }
 

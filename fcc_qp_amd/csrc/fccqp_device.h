@@ -52,8 +52,15 @@ constexpr int kFlagEqualityOnly = 8;
 constexpr int kFlagPresolveCod = 16;
 
 // ---- generic kernel (fccqp_generic.hip) -----------------------------------------------------
-// Largest KKT size N = n + m the generic kernel handles (8 register slots x 64 lanes).
-constexpr int kGenericMaxN = 512;
+// Largest KKT size N = n + m the generic kernel handles (4 register slots x 64 lanes; the reference's
+// shapes are N = 98 and, in BASELINE configs[3], N = 174).  An 8-slot instantiation for N up to 512
+// existed in round 1 and was withdrawn in round 2: its first GPU tests (N = 260 ... 512) returned
+// sporadically wrong iterates -- the KKT factor it left in memory was right, the triangular sweeps
+// that read it were not; which runs failed changed from GPU box to GPU box and from build to build,
+// bounds-checked accesses found nothing out of range, and agent-scope fences, a rewrite of the
+// factorisation with static row ownership and exact-slot instantiations each only moved the failures
+// (DESIGN.md section 7).  fccqp_create returns FCCQP_ERR_UNSUPPORTED beyond this size.
+constexpr int kGenericMaxN = 256;
 // Bytes of dynamic LDS the generic kernel needs when the packed KKT lives in LDS.
 size_t generic_lds_bytes(int n, int m, int nc);
 // Doubles of global workspace per block when the packed KKT does not fit in LDS (else 0).

@@ -126,10 +126,15 @@ __device__ __forceinline__ double wave_max(double v) {
 // reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25, evaluated for ONE
 // component of the contact force (every lane of a contact triple calls it with the same
 // (fx, fy, fz) and its own component v = f[comp]).  Same three branches and the same f_z == 0
-// quirk.  The side-of-cone branch evaluates (r.f / r.r) r instead of normalising r first
-// ((r/|r|).f (r/|r|), :22-23) -- identical in exact arithmetic -- and gets 1/|f_xy| and 1/(r.r)
-// from v_rsq_f64 / v_rcp_f64 + Newton steps (<= 1-2 ulp) instead of IEEE sqrt/div: those are
-// ~15-instruction sequences executed by every lane of the wave on every ADMM iteration.
+// quirk.  The side-of-cone branch of the reference normalises the ray r = (k f_x, k f_y, f_z),
+// k = mu f_z / |f_xy|, and returns (r^ . f) r^ (:20-23).  With |r|^2 = f_z^2 (1 + mu^2) and
+// r . f = f_z (mu |f_xy| + f_z) the same vector is
+//     t (mu f_xy / |f_xy|, 1),     t = (mu |f_xy| + f_z) / (1 + mu^2)
+// -- the textbook second-order-cone projection: one reciprocal square root per iteration
+// (v_rsq_f64 + two Newton steps, <= 1-2 ulp) and a per-lane constant kc = 1 / (1 + mu^2) (z
+// component) or mu / (1 + mu^2) (x, y) computed once, instead of the rsqrt + reciprocal + ~12 more
+// dependent operations of the literal form, on every lane of the wave on every ADMM iteration.
+// f_z == 0 exactly: Eigen's normalize() leaves the zero ray alone and the reference returns 0.
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
   r = fma(fma(-d, r, 1.0), r, r);
@@ -145,21 +150,21 @@ __device__ __forceinline__ double fast_rsqrt(double a) {  // a > 0
   r = fma(0.5 * r, e, r);
   return r;
 }
-__device__ __forceinline__ double project_cone_component(double fx, double fy, double fz, double mu,
+__device__ __forceinline__ double cone_lane_constant(double mu, bool is_z) {
+  const double c = 1.0 / fma(mu, mu, 1.0);
+  return is_z ? c : mu * c;
+}
+__device__ __forceinline__ double project_cone_component(double fx, double fy, double fz, double mu, double kc,
                                                          double v, bool is_z) {
   const double nxy2 = fx * fx + fy * fy;
-  const bool flat = !(nxy2 > 0.0);                      // f_xy == 0: inside if f_z >= 0, else origin
+  const bool flat = !(nxy2 > 0.0);                      // f_xy == 0: inside if mu f_z >= 0, else origin
   const double rs = fast_rsqrt(flat ? 1.0 : nxy2);
   const double nxy = flat ? 0.0 : nxy2 * rs;
   const bool inside = mu * fz >= nxy;                   // :10-12
   const bool polar = fz < -mu * nxy;                    // :15-17
-  const double ratio = mu * fz * rs;                    // :20   mu f_z / |f_xy|
-  // ray r = (ratio fx, ratio fy, fz):  r.r = ratio^2 |f_xy|^2 + fz^2,  r.f = ratio |f_xy|^2 + fz^2
-  const double fz2 = fz * fz;
-  const double z2 = fma(ratio * ratio, nxy2, fz2);
-  const double dot = fma(ratio, nxy2, fz2);
-  const double sc = (z2 > 0.0) ? dot * fast_rcp(z2) : 0.0;   // zero ray (f_z == 0): Eigen's normalize() no-op -> 0
-  const double side = sc * (is_z ? 1.0 : ratio) * v;
+  const double t = fma(mu, nxy, fz) * kc;               // :20-23, see above
+  const double dir = is_z ? 1.0 : rs * v;
+  const double side = (fz == 0.0) ? 0.0 : t * dir;      // zero ray: Eigen's normalize() no-op -> 0
   return inside ? v : (polar ? 0.0 : side);
 }
 
@@ -940,6 +945,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     // a VGPR copy costs one v_cmp per use at most (and is parked in an AGPR across P3 for free).
     int var_i = isvar ? 1 : 0, cone_i = is_cone ? 1 : 0, z_i = (ccomp == 2) ? 1 : 0;
     double eps_b = a.eps_bound, eps_f = a.eps_fcone;
+    const double vkc = cone_lane_constant(vmu, ccomp == 2);
     asm volatile("" : "+v"(var_i), "+v"(cone_i), "+v"(z_i), "+v"(eps_b), "+v"(eps_f));
 #pragma nounroll
     for (int iter = 0; iter < a.max_iter; ++iter) {
@@ -984,7 +990,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       }
       if (cone_i != 0) {
         const int base = s0 + 3 * cidx;
-        lcbar = project_cone_component(vbuf[base], vbuf[base + 1], vbuf[base + 2], vmu, x + mulc, z_i != 0);
+        lcbar = project_cone_component(vbuf[base], vbuf[base + 1], vbuf[base + 2], vmu, vkc, x + mulc, z_i != 0);
         lr = x - lcbar;                   // :96
         mulc += lr;                       // :102
       }

@@ -115,10 +115,15 @@ __device__ __forceinline__ double fast_rsqrt(double a) {  // a > 0; Newton twice
 }
 // reference: project_to_friction_cone(Vector3d, mu), constraint_utils.cpp:5-25, for ONE component
 // v = f[comp] of the contact force (every lane of a contact triple calls it with the same
-// (fx, fy, fz)).  Same three branches, same f_z == 0 quirk; the side-of-cone branch evaluates
-// (r.f / r.r) r instead of normalising r first (:22-23), with v_rsq / v_rcp + Newton instead of the
-// IEEE sqrt / div sequences (same formulation as the fused kernel, fccqp_fused_impl.h).
-__device__ __forceinline__ double project_cone_component(double fx, double fy, double fz, double mu,
+// (fx, fy, fz)).  Same three branches, same f_z == 0 quirk; the side-of-cone branch in the form
+// t (mu f_xy / |f_xy|, 1), t = (mu |f_xy| + f_z) / (1 + mu^2), with the per-lane constant
+// kc = 1 / (1 + mu^2) (z) or mu / (1 + mu^2) (x, y) -- same formulation as the fused kernel, derivation
+// in fccqp_fused_impl.h.
+__device__ __forceinline__ double cone_lane_constant(double mu, bool is_z) {
+  const double c = 1.0 / fma(mu, mu, 1.0);
+  return is_z ? c : mu * c;
+}
+__device__ __forceinline__ double project_cone_component(double fx, double fy, double fz, double mu, double kc,
                                                          double v, bool is_z) {
   const double nxy2 = fx * fx + fy * fy;
   const bool flat = !(nxy2 > 0.0);
@@ -126,12 +131,9 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
   const double nxy = flat ? 0.0 : nxy2 * rs;
   const bool inside = mu * fz >= nxy;                   // :10-12
   const bool polar = fz < -mu * nxy;                    // :15-17
-  const double ratio = mu * fz * rs;                    // :20
-  const double fz2 = fz * fz;
-  const double z2 = fma(ratio * ratio, nxy2, fz2);
-  const double dot = fma(ratio, nxy2, fz2);
-  const double sc = (z2 > 0.0) ? dot * fast_rcp(z2) : 0.0;   // zero ray: Eigen's normalize() no-op -> 0
-  const double side = sc * (is_z ? 1.0 : ratio) * v;
+  const double t = fma(mu, nxy, fz) * kc;               // :20-23
+  const double dir = is_z ? 1.0 : rs * v;
+  const double side = (fz == 0.0) ? 0.0 : t * dir;      // zero ray: Eigen's normalize() no-op -> 0
   return inside ? v : (polar ? 0.0 : side);
 }
 
@@ -1365,13 +1367,14 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     for (int t = 0; t < SLOTS; ++t) { xbar[t] = x[t]; lcbar[t] = x[t]; }  // :74-75
     // per-lane constants of the projections, and the last residuals (for the reported norms)
     int cidx[SLOTS], ccomp[SLOTS];
-    double vmu[SLOTS], xr_last[SLOTS], lr_last[SLOTS];
+    double vmu[SLOTS], vkc[SLOTS], xr_last[SLOTS], lr_last[SLOTS];
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) {
       const int i = lane + kWave * t;
       cidx[t] = is_cone[t] ? (i - s0) / 3 : 0;
       ccomp[t] = is_cone[t] ? (i - s0) - 3 * cidx[t] : 0;
       vmu[t] = is_cone[t] ? mu[cidx[t]] : 0.0;
+      vkc[t] = cone_lane_constant(vmu[t], ccomp[t] == 2);
       xr_last[t] = 0.0; lr_last[t] = 0.0;
     }
 
@@ -1589,7 +1592,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
         }
         if (is_cone[t]) {
           const int base = 3 * cidx[t];
-          lcbar[t] = project_cone_component(cone_buf[base], cone_buf[base + 1], cone_buf[base + 2], vmu[t],
+          lcbar[t] = project_cone_component(cone_buf[base], cone_buf[base + 1], cone_buf[base + 2], vmu[t], vkc[t],
                                             x[t] + mulc[t], ccomp[t] == 2);
           lr_last[t] = x[t] - lcbar[t];                   // :96
           mulc[t] += lr_last[t];                          // :102
@@ -1781,7 +1784,7 @@ static hipError_t launch_generic_blocks(const KernelArgs &a, size_t lds_limit, i
     case 2: return launch_slots<2, TIN>(a, in_lds, lds, blocks, stream);
     case 3: return launch_slots<3, TIN>(a, in_lds, lds, blocks, stream);
     case 4: return launch_slots<4, TIN>(a, in_lds, lds, blocks, stream);
-    default: return launch_slots<8, TIN>(a, in_lds, lds, blocks, stream);
+    default: return hipErrorInvalidValue;            // N > kGenericMaxN is refused at fccqp_create
   }
 }
 

@@ -221,6 +221,14 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def("set_kernel", &FCCQPBatch::set_kernel)
       .def("kernel_in_use", &FCCQPBatch::kernel_in_use)
       .def_property_readonly("batch", &FCCQPBatch::batch)
+      .def_property_readonly("num_vars", &FCCQPBatch::num_vars)
+      .def_property_readonly("num_equality_constraints", &FCCQPBatch::num_equality_constraints)
+      .def_property_readonly("nc", &FCCQPBatch::nc)
+      .def_property_readonly("device", [](const FCCQPBatch &self) {
+        int dev = 0;
+        fccqp_get_shape(self.handle(), nullptr, nullptr, nullptr, nullptr, nullptr, &dev);
+        return dev;
+      })
       .def(
           "Solve",
           [](FCCQPBatch &self, const py::object &Q, const py::object &b, const py::object &A_eq,
@@ -278,6 +286,46 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
              return d;
            },
            "Device addresses of the last solve's results (see include/fccqp.h).");
+
+  // ---- one host batch over several GPUs (new) --------------------------------
+  py::class_<fcc_qp::FCCQPSharded>(m, "FCCQPSharded")
+      .def(py::init<int, int, int, int, int, const std::vector<int> &>(), py::arg("num_vars"),
+           py::arg("num_equality_constraints"), py::arg("nc"), py::arg("lambda_c_start"),
+           py::arg("batch"), py::arg("devices"))
+      .def("set_options", &fcc_qp::FCCQPSharded::set_options)
+      .def("set_warm_start", &fcc_qp::FCCQPSharded::set_warm_start)
+      .def("set_kernel", &fcc_qp::FCCQPSharded::set_kernel)
+      .def_property_readonly("batch", &fcc_qp::FCCQPSharded::batch)
+      .def_property_readonly("shards", &fcc_qp::FCCQPSharded::shards)
+      .def("shard_begin", &fcc_qp::FCCQPSharded::shard_begin)
+      .def("device_of", &fcc_qp::FCCQPSharded::device_of)
+      .def(
+          "Solve",
+          [](fcc_qp::FCCQPSharded &self, const py::object &Qo, const py::object &bo, const py::object &Ao,
+             const py::object &beo, const py::object &fo, const py::object &lo, const py::object &uo) {
+            using arr = py::array_t<double, py::array::c_style | py::array::forcecast>;
+            const arr Q = arr::ensure(Qo), b = arr::ensure(bo), A_eq = arr::ensure(Ao), b_eq = arr::ensure(beo),
+                      fr = arr::ensure(fo), lb = arr::ensure(lo), ub = arr::ensure(uo);
+            if (!Q || !b || !A_eq || !b_eq || !fr || !lb || !ub)
+              throw py::type_error("FCCQPSharded.Solve: arguments must be convertible to float64 arrays");
+            const py::ssize_t B = self.batch(), n = self.num_vars(), mm = self.num_equality_constraints();
+            expect_shape_t<double>(Q, {B, n, n}, "Q");
+            expect_shape_t<double>(b, {B, n}, "b");
+            if (mm > 0) expect_shape_t<double>(A_eq, {B, mm, n}, "A_eq");
+            if (mm > 0) expect_shape_t<double>(b_eq, {B, mm}, "b_eq");
+            expect_shape_t<double>(lb, {B, n}, "lb");
+            expect_shape_t<double>(ub, {B, n}, "ub");
+            if (!(fr.ndim() == 2 && fr.shape(0) == B)) throw py::value_error("friction_coeffs must have shape (batch, k)");
+            const int k = (int)fr.shape(1);
+            if (k < self.nc() / 3) throw py::index_error("friction_coeffs has fewer than nc/3 entries per instance");
+            py::gil_scoped_release release;
+            self.Solve(Q.data(), b.data(), A_eq.data(), b_eq.data(), fr.data(), k, lb.data(), ub.data());
+          },
+          py::arg("Q"), py::arg("b"), py::arg("A_eq"), py::arg("b_eq"), py::arg("friction_coeffs"),
+          py::arg("lb"), py::arg("ub"),
+          "Splits the instance-major host batch over the shards (one host thread per shard), solves, waits.")
+      .def("GetSolution", &fcc_qp::FCCQPSharded::GetSolution)
+      .def("LastKernelMilliseconds", &fcc_qp::FCCQPSharded::LastKernelMilliseconds);
 
   m.def("device_count", &fccqp_device_count);
   m.attr("KERNEL_AUTO") = (int)FCCQP_KERNEL_AUTO;

@@ -136,6 +136,22 @@ int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double 
                 const double *b_eq, const double *friction_coeffs, int n_friction,
                 const double *lb, const double *ub);
 
+/* Asynchronous host-pointer form: the copies and the kernel(s) are enqueued on the solver's own
+ * stream and the call returns at once.  The seven host arrays must stay valid and unmodified until
+ * fccqp_synchronize() / fccqp_get_solution() on this handle, and should be page-locked
+ * (fccqp_host_register below, or hipHostMalloc) -- from pageable memory the HIP runtime copies
+ * synchronously and nothing overlaps.  This is what lets a caller keep several handles in flight:
+ * the H2D copy of one batch, the kernel of another and the D2H copy of a third overlap (bench.py's
+ * `end_to_end` leg; SURVEY.md 8d timing protocol).  n_friction must equal nc/3 here. */
+int fccqp_solve_async(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
+                      const double *b_eq, const double *friction_coeffs, int n_friction,
+                      const double *lb, const double *ub);
+/* Page-lock / release a host range for DMA (thin wrappers over hipHostRegister/Unregister, so
+ * that a caller of this ABI needs no HIP headers).  The reference has no counterpart: its inputs
+ * never leave the host (src/fcc_qp.cpp:146-150 copies them into Eigen members). */
+int fccqp_host_register(void *ptr, size_t bytes);
+int fccqp_host_unregister(void *ptr);
+
 /* Device-pointer form: the seven arrays are already resident in HBM on the solver's device
  * (instance-major, friction stride nc/3).  Enqueues on `stream` and returns without waiting.
  * `stream` is a hipStream_t: NULL is HIP's default (null) stream, as everywhere in HIP;
@@ -165,6 +181,10 @@ int fccqp_synchronize(fccqp_solver *s);
 /* Copies z[batch][n] and details[batch] to the host (either may be NULL).  Waits for the solve. */
 int fccqp_get_solution(fccqp_solver *s, double *z, fccqp_details *details);
 
+/* z only, into page-locked host memory, enqueued behind the solve on the solver's stream; returns
+ * at once.  fccqp_synchronize() waits for it. */
+int fccqp_get_z_async(fccqp_solver *s, double *z_pinned);
+
 /* Device-resident results of the last solve (valid until the next solve / destroy):
  * z[batch][n] (f64); n_iter[batch], flags[batch] (i32);
  * metrics[4][batch] (f64) = residual_bounds, residual_cone, bounds_viol, cone_viol;
@@ -191,6 +211,14 @@ int fccqp_phase_seconds(fccqp_solver *s, double out[8]);
  * 8 * batch * (n^2 + m*n + 4n + m + nc/3), plus the warm-start state when warm.  After an
  * fp32-storage solve the seven inputs count 4 bytes per element (z and the state stay 8). */
 int fccqp_algorithmic_bytes(const fccqp_solver *s, long long *bytes);
+
+/* ---- debugging aids ------------------------------------------------------------------------- */
+/* Copies up to `count` doubles of the solver's global workspace to the host (the per-block KKT
+ * factor of shapes too large for LDS, N > 198; the staged rho*G of the generic kernel's operator
+ * iterations otherwise) and returns the number available in *available (0: no workspace).  Lets a
+ * test compare the factor a kernel left behind with one computed on the host.  Environment:
+ * FCCQP_DEBUG_POISON=1 fills every fresh device allocation with NaN bit patterns. */
+int fccqp_debug_read_workspace(fccqp_solver *s, double *out, long long count, long long *available);
 
 #ifdef __cplusplus
 }

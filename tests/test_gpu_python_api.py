@@ -152,3 +152,148 @@ def test_harness_reproduces_reference_loop_and_series(oracle, tmp_path):
     assert np.allclose(bat["lambda_c"][0], seq["lambda_c"][0], rtol=1e-9, atol=1e-9)
     import json
     assert json.load(open(str(tmp_path / "r.json")))["sequence"]["count"] == 10
+
+
+# ---- zero-copy API: __dlpack__ in, tensors out, against the oracle ----------------
+class _DLPackOnly:
+    """A foreign device array: exports nothing but the DLPack protocol."""
+
+    def __init__(self, t):
+        self._t = t
+
+    def __dlpack__(self, stream=None):
+        return self._t.__dlpack__(stream=stream) if stream is not None else self._t.__dlpack__()
+
+    def __dlpack_device__(self):
+        return self._t.__dlpack_device__()
+
+
+def test_dlpack_in_tensors_out_match_oracle(oracle):
+    import torch
+    import fcc_qp_amd as F
+    nb = 96
+    B = P.workload("W-mix", nb, P.WALKING)
+    z_ref, it_ref, det_ref, _ = oracle.solve_batch(P.WALKING.ctor_args, P.HARNESS_OPTIONS, *B.arrays(), nthreads=8)
+    bs = F.FCCQPBatch(60, 38, 12, 38, nb); bs.set_options(harness_options(F))
+    tens = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in B.arrays()]
+    F.solve_tensors(bs, *[_DLPackOnly(t) for t in tens])           # any __dlpack__ producer
+    out = F.result_tensors(bs)                                      # torch tensors aliasing the solver's buffers
+    assert out["z"].is_cuda and out["z"].shape == (nb, 60) and out["z"].dtype == torch.float64
+    assert out["z"].data_ptr() == bs.device_pointers()["z"]         # no copy
+    torch.cuda.synchronize()
+    z = out["z"].cpu().numpy(); it = out["n_iter"].cpu().numpy()
+    err = np.max(np.abs(z - z_ref), axis=1) / (1 + np.max(np.abs(z_ref), axis=1))
+    assert err.max() <= 1e-9 and np.max(np.abs(it - it_ref)) <= 1
+    for key, ref in (("bounds_viol", [d.bounds_viol for d in det_ref]), ("friction_cone_viol", [d.friction_cone_viol for d in det_ref]),
+                     ("eps_bounds", [d.admm_residual_bounds for d in det_ref]),
+                     ("eps_friction_cone", [d.admm_residual_friction_cone for d in det_ref])):
+        got = out[key].cpu().numpy(); ref = np.asarray(ref)
+        same = it == it_ref
+        assert np.all(np.abs(got - ref)[same] <= 1e-6 * (1 + np.abs(ref)[same])), key
+    # results stay on the device for the next consumer: hand z on through DLPack, reduce there
+    z2 = torch.from_dlpack(out["z"])
+    assert z2.data_ptr() == out["z"].data_ptr()
+    assert abs(float(z2.abs().max()) - np.abs(z).max()) <= 1e-9 * (1 + np.abs(z).max())
+    # the tensors keep the solver alive
+    del bs
+    assert np.array_equal(out["z"].cpu().numpy(), z)
+
+
+def test_solve_tensors_validates_shapes_and_device():
+    import torch
+    import fcc_qp_amd as F
+    nb = 8
+    B = P.workload("W-sat", nb, P.WALKING)
+    bs = F.FCCQPBatch(60, 38, 12, 38, nb); bs.set_options(harness_options(F))
+    assert (bs.batch, bs.num_vars, bs.num_equality_constraints, bs.nc, bs.device) == (nb, 60, 38, 12, 0)
+    tens = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in B.arrays()]
+    bad = list(tens); bad[0] = tens[0][:-1]                               # one instance short
+    with pytest.raises(ValueError, match="Q has shape"):
+        F.solve_tensors(bs, *bad)
+    bad = list(tens); bad[4] = tens[4][0]                                 # one shared friction row: host path only
+    with pytest.raises(ValueError, match="friction_coeffs has shape"):
+        F.solve_tensors(bs, *bad)
+    bad = list(tens); bad[2] = tens[2].transpose(1, 2)                    # right numel, wrong layout
+    with pytest.raises(ValueError):
+        F.solve_tensors(bs, *bad)
+    bad = list(tens); bad[1] = tens[1].cpu()
+    with pytest.raises(ValueError, match="not on a GPU"):
+        F.solve_tensors(bs, *bad)
+    with pytest.raises(TypeError):
+        F.solve_tensors(bs, B.Q.tolist(), *tens[1:])
+    F.solve_tensors(bs, *tens); torch.cuda.synchronize()                  # the good call still works
+
+
+# ---- one host batch over several handles (SURVEY.md 8e) -----------------------------------------------
+def test_sharded_solve_equals_unsharded_bit_for_bit(oracle):
+    """Two shards on device 0 (this box has one GPU): [0, B/2) and [B/2, B) solved by two handles
+    from two host threads, gathered into one result -- bit-identical to one handle solving all."""
+    import fcc_qp_amd as F
+    nb = 100                                        # not a multiple of 3: ragged shards below
+    B = P.workload("W-mix", nb, P.WALKING)
+    one = F.FCCQPBatch(60, 38, 12, 38, nb); one.set_options(harness_options(F))
+    one.Solve(*B.arrays()); ref = one.GetSolution()
+    for devices in ([0, 0], [0, 0, 0]):
+        sh = F.FCCQPSharded(60, 38, 12, 38, nb, devices); sh.set_options(harness_options(F))
+        assert sh.shards == len(devices) and sh.batch == nb
+        assert [sh.shard_begin(g) for g in range(len(devices) + 1)] == [nb * g // len(devices) for g in range(len(devices) + 1)]
+        sh.Solve(*B.arrays()); got = sh.GetSolution()
+        assert np.array_equal(got.z, ref.z) and np.array_equal(got.n_iter, ref.n_iter)
+        assert np.array_equal(got.flags, ref.flags) and np.array_equal(got.bounds_viol, ref.bounds_viol)
+        assert sh.LastKernelMilliseconds() > 0
+        # warm-start state stays on the owning handle: a warm chain equals the unsharded warm chain
+        B2 = P.workload("W-mix", nb, P.WALKING, seed0=4000)
+        sh.set_warm_start(True); sh.Solve(*B2.arrays()); w = sh.GetSolution()
+        one.set_warm_start(True); one.Solve(*B2.arrays()); wref = one.GetSolution()
+        assert np.array_equal(w.z, wref.z) and np.array_equal(w.n_iter, wref.n_iter)
+        one.set_warm_start(False); one.Solve(*B.arrays())
+    z_ref, it_ref, _, _ = oracle.solve_batch(P.WALKING.ctor_args, P.HARNESS_OPTIONS, *B.arrays(), nthreads=8)
+    err = np.max(np.abs(ref.z - z_ref), axis=1) / (1 + np.max(np.abs(z_ref), axis=1))
+    assert err.max() <= 1e-9
+    with pytest.raises(Exception):
+        F.FCCQPSharded(60, 38, 12, 38, 2, [0, 0, 0])          # fewer instances than shards
+    if F.device_count() == 1:
+        with pytest.raises(F.FCCQPError):
+            F.FCCQPSharded(60, 38, 12, 38, 8, [0, 1])          # no such device
+
+
+def test_async_host_solve_from_pinned_memory(oracle):
+    """fccqp_solve_async + fccqp_get_z_async on page-locked buffers: two handles in flight, results
+    equal to the synchronous path."""
+    from tests import capi as C
+    import ctypes
+    L = C.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.fccqp_solve_async.argtypes = [ctypes.c_void_p, dp, dp, dp, dp, dp, ctypes.c_int, dp, dp]
+    L.fccqp_get_z_async.argtypes = [ctypes.c_void_p, dp]
+    L.fccqp_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.fccqp_host_unregister.argtypes = [ctypes.c_void_p]
+    nb = 256
+    batches = [P.workload("W-mix", nb, P.WALKING, seed0=1000 + 500 * k) for k in range(2)]
+    solvers = [C.Solver(*P.WALKING.ctor_args, batch=nb) for _ in range(2)]
+    zs = [np.zeros((nb, 60)) for _ in range(2)]
+    pinned = []
+    for k in range(2):
+        solvers[k].set_options(**P.HARNESS_OPTIONS)
+        for a in list(batches[k].arrays()) + [zs[k]]:
+            assert L.fccqp_host_register(a.ctypes.data, a.nbytes) == C.OK
+            pinned.append(a)
+    for k in range(2):                                        # both enqueued before either is waited for
+        arrs = batches[k].arrays()
+        rc = L.fccqp_solve_async(solvers[k].h, C._p(arrs[0]), C._p(arrs[1]), C._p(arrs[2]), C._p(arrs[3]), C._p(arrs[4]), 4,
+                                 C._p(arrs[5]), C._p(arrs[6]))
+        assert rc == C.OK
+        assert L.fccqp_get_z_async(solvers[k].h, C._p(zs[k])) == C.OK
+    for k in range(2):
+        assert L.fccqp_synchronize(solvers[k].h) == C.OK
+        z_sync, d = solvers[k].solution()
+        assert np.array_equal(zs[k], z_sync)
+        z_ref, it_ref, _, _ = oracle.solve_batch(P.WALKING.ctor_args, P.HARNESS_OPTIONS, *batches[k].arrays(), nthreads=8)
+        err = np.max(np.abs(zs[k] - z_ref), axis=1) / (1 + np.max(np.abs(z_ref), axis=1))
+        assert err.max() <= 1e-9
+    arrs = batches[0].arrays()                                # a stride of friction rows is a host-path feature only
+    wide = np.ascontiguousarray(np.concatenate([arrs[4], arrs[4]], axis=1))
+    assert L.fccqp_solve_async(solvers[0].h, C._p(arrs[0]), C._p(arrs[1]), C._p(arrs[2]), C._p(arrs[3]), C._p(wide), 8,
+                               C._p(arrs[5]), C._p(arrs[6])) == C.ERR_FRICTION
+    for a in pinned:
+        assert L.fccqp_host_unregister(a.ctypes.data) == C.OK

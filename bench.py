@@ -58,8 +58,16 @@ def parse_args():
     ap.add_argument("--inputs", default="f64", choices=["f64", "f32"],
                     help="storage type of the resident inputs; f32 = BASELINE configs[2]'s fp32-storage "
                          "path (widened on load, arithmetic stays fp64; the batch is the float-rounded problem)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every GPU gets --batch instances (default); strong: --batch-global instances are "
+                         "split over the GPUs, rank g taking [g B / G, (g + 1) B / G)  (SURVEY.md 8e)")
+    ap.add_argument("--batch-global", type=int, default=BATCH_PER_GPU,
+                    help="global batch for --scaling strong (4096 = the metric's batch; 65536 = BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements appended to the JSON line (W-psd, W-mix, paper/warm, "
+                         "fp32 storage, large shape, end-to-end from pinned host memory); they run on 1 GPU only")
     return ap.parse_args()
 
 
@@ -131,6 +139,156 @@ def cpu_baseline(shape, options, batch_obj, log):
     }
 
 
+def _timed_steps(torch, step, steps, warmup):
+    """W untimed + K timed steps of `step` on torch's current stream; (wall seconds, kernel ms per step)."""
+    for _ in range(warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record(); step(); e1.record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, [e0.elapsed_time(e1) for e0, e1 in ev]
+
+
+def _parity(O, shape, options, batch, z, n_iter, k):
+    import numpy as np
+    z_ref, it_ref, _, _ = O.solve_batch(shape.ctor_args, options, *batch.slice(0, k).arrays(), nthreads=8)
+    err = np.max(np.abs(z[:k] - z_ref), axis=1) / (1.0 + np.max(np.abs(z_ref), axis=1))
+    dn = np.abs(np.asarray(n_iter[:k]).astype(np.int64) - it_ref.astype(np.int64))
+    return {"sample": int(k), "max_rel_err": float(err.max()), "max_dn_iter": int(dn.max())}
+
+
+def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup=3):
+    """The numbers beside the headline that DESIGN.md quotes, measured in the same process so that
+    the driver's BENCH json carries them (`extra_keys`): each is {value [solves/s], ms_per_step,
+    kernel_ms_mean, roofline_frac, parity vs the oracle on a sample, ...}.  1 GPU, batch 4096."""
+    import numpy as np
+    out = {}
+    nb = BATCH_PER_GPU
+
+    def run(name, shape, wl, options, kernel=None, warm=False, f32=False, distinct=256, parity_k=64, seed0=1000,
+            steps=steps, warmup=warmup):
+        t0 = time.time()
+        batch = P.workload(wl, nb, shape, seed0=seed0, distinct=distinct)
+        if f32:
+            batch = P.Batch(*(a.astype(np.float32).astype(np.float64) for a in batch.arrays()))
+        solver = F.FCCQPBatch(*shape.ctor_args, nb, dev_index)
+        o = F.FCCQPOptions()
+        o.max_iter, o.rho, o.eps_fcone, o.eps_bound = (options["max_iter"], options["rho"], options["eps_fcone"], options["eps_bound"])
+        solver.set_options(o)
+        if kernel is not None:
+            solver.set_kernel(kernel)
+        tens = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in batch.arrays()]
+        if f32:
+            tens = [t.float() for t in tens]
+        step = lambda: F.solve_tensors(solver, *tens)
+        step(); torch.cuda.synchronize()
+        cold = solver.GetSolution()
+        par = _parity(O, shape, options, batch, cold.z, cold.n_iter, parity_k)
+        if warm:
+            solver.set_warm_start(True)
+        wall, kms = _timed_steps(torch, step, steps, warmup)
+        sol = solver.GetSolution()
+        it = np.asarray(sol.n_iter)
+        ab = solver.AlgorithmicBytes()
+        mean_ms = float(np.mean(kms))
+        rec = {"value": nb * steps / wall, "unit": "solves/s", "ms_per_step": 1e3 * wall / steps, "kernel_ms_mean": mean_ms,
+               "roofline_frac": ab / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": ab,
+               "kernel": {1: "generic", 2: "fused"}[solver.kernel_in_use()], "parity": par,
+               "n_iter_mean": float(it.mean()), "n_iter_at_max_frac": float(np.mean(it == options["max_iter"])),
+               "workload": f"{wl} FCCQP{tuple(shape.ctor_args)} {'warm' if warm else 'cold'} max_iter={options['max_iter']}"
+                           f"{' fp32 storage' if f32 else ''}, {distinct} distinct instances tiled to {nb}"}
+        if par["max_rel_err"] > 1e-6 or par["max_dn_iter"] > 1:
+            rec["parity_failed"] = True
+        out[name] = rec
+        log(f"[bench] {name}: {rec['value'] / 1e6:.3f} M solves/s, kernel {mean_ms:.3f} ms, parity {par} ({time.time() - t0:.1f} s)")
+        return solver, batch, sol
+
+    # semi-definite cost (no force regularisation): the reference's own presolve takes its COD branch here
+    run("w_psd", P.WALKING, "W-psd", P.HARNESS_OPTIONS)
+    # half the instances exit early: the n_iter histogram SURVEY.md 8d asks for
+    _, _, sol = run("w_mix", P.WALKING, "W-mix", P.HARNESS_OPTIONS)
+    it = np.asarray(sol.n_iter)
+    edges = [0, 1, 2, 5, 10, 20, 50, 100, 101]
+    out["w_mix"]["n_iter_hist"] = {f"[{edges[i]},{edges[i + 1]})": int(np.sum((it >= edges[i]) & (it < edges[i + 1]))) for i in range(len(edges) - 1)}
+    # the paper's deployment: max_iter 15, eps 1e-4, warm start (fccqp.pdf Table 1)
+    run("paper_warm", P.WALKING, "W-sat", P.PAPER_OPTIONS, warm=True)
+    # BASELINE configs[2]: fp32 storage of the inputs, fp64 arithmetic
+    run("f32_storage", P.WALKING, "W-sat", P.HARNESS_OPTIONS, f32=True)
+    # the walking shape on the any-shape kernel
+    run("generic_kernel", P.WALKING, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_GENERIC)
+    # BASELINE configs[3]: 36-DoF / 8-contact shape (generic kernel, four waves per QP)
+    run("large_shape", P.LARGE, "W-sat", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
+    out["end_to_end"] = end_to_end(P, O, dev_index, log)
+    return out
+
+
+def end_to_end(P, O, dev_index, log, handles=3, rounds=12):
+    """Host memory in, host memory out (SURVEY.md 8d timing protocol): page-locked input and result
+    buffers, `handles` solver handles round-robin so that the H2D copy of one batch, the kernel of
+    another and the D2H copy of z of a third overlap (fccqp_solve_async / fccqp_get_z_async).  Per
+    4096-batch 202 MB cross PCIe: this rate is bounded by the link, not by the kernel, and is never
+    the headline `value`."""
+    import numpy as np
+    from tests import capi as C
+    L = C.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.fccqp_solve_async.argtypes = [ctypes.c_void_p, dp, dp, dp, dp, dp, ctypes.c_int, dp, dp]
+    L.fccqp_get_z_async.argtypes = [ctypes.c_void_p, dp]
+    L.fccqp_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.fccqp_host_unregister.argtypes = [ctypes.c_void_p]
+    nb, shape, options = BATCH_PER_GPU, P.WALKING, P.HARNESS_OPTIONS
+    batch = P.workload("W-sat", nb, shape, distinct=256)
+    ins = [[np.ascontiguousarray(a.copy()) for a in batch.arrays()] for _ in range(handles)]
+    zs = [np.zeros((nb, shape.n)) for _ in range(handles)]
+    solvers = [C.Solver(*shape.ctor_args, batch=nb, device=dev_index) for _ in range(handles)]
+    pinned = []
+    for k in range(handles):
+        solvers[k].set_options(**options)
+        for a in ins[k] + [zs[k]]:
+            if L.fccqp_host_register(a.ctypes.data, a.nbytes) != C.OK:
+                raise RuntimeError("fccqp_host_register failed")
+            pinned.append(a)
+    nf = shape.nc // 3
+
+    def submit(k):
+        a = ins[k]
+        rc = L.fccqp_solve_async(solvers[k].h, C._p(a[0]), C._p(a[1]), C._p(a[2]), C._p(a[3]), C._p(a[4]), nf, C._p(a[5]), C._p(a[6]))
+        rc = rc or L.fccqp_get_z_async(solvers[k].h, C._p(zs[k]))
+        if rc != C.OK:
+            raise RuntimeError(f"async solve failed: {rc}")
+
+    for k in range(handles):                       # fill the pipeline (also the warm-up)
+        submit(k)
+    for k in range(handles):
+        L.fccqp_synchronize(solvers[k].h)
+    t0 = time.perf_counter()
+    for k in range(handles):
+        submit(k)
+    for r in range(rounds):
+        k = r % handles
+        L.fccqp_synchronize(solvers[k].h)          # batch r is back in host memory ...
+        if r + handles < rounds + handles:
+            submit(k)                              # ... and its handle takes the next one
+    for k in range(handles):
+        L.fccqp_synchronize(solvers[k].h)
+    wall = time.perf_counter() - t0
+    done = rounds + handles
+    z_ref, it_ref, _, _ = O.solve_batch(shape.ctor_args, options, *batch.slice(0, 64).arrays(), nthreads=8)
+    err = max(float(np.max(np.abs(z[:64] - z_ref) / (1.0 + np.max(np.abs(z_ref), axis=1, keepdims=True)))) for z in zs)
+    for a in pinned:
+        L.fccqp_host_unregister(a.ctypes.data)
+    bytes_per_batch = sum(a.nbytes for a in ins[0]) + zs[0].nbytes
+    rec = {"value": nb * done / wall, "unit": "solves/s", "ms_per_batch": 1e3 * wall / done, "handles": handles,
+           "pcie_gb_per_s": bytes_per_batch * done / wall / 1e9, "host_bytes_per_batch": bytes_per_batch,
+           "parity": {"sample": 64, "max_rel_err": err},
+           "what": "page-locked host buffers -> H2D + kernel + D2H of z, batches pipelined over the handles"}
+    log(f"[bench] end_to_end: {rec['value'] / 1e6:.3f} M solves/s, {rec['pcie_gb_per_s']:.1f} GB/s over PCIe, max rel err {err:.1e}")
+    return rec
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -159,10 +317,15 @@ def main():
 
     shape = P.WALKING if args.shape == "walking" else P.LARGE
     options = dict(P.HARNESS_OPTIONS if args.options == "harness" else P.PAPER_OPTIONS)
-    nb = args.batch
+    if args.scaling == "strong":
+        # one global batch, instance i = seed 1000 + i, rank g owning [g B / G, (g + 1) B / G)
+        lo, hi = S.shard_bounds(args.batch_global, world, rank)
+        nb, seed0 = hi - lo, 1000 + lo
+    else:
+        nb, seed0 = args.batch, S.rank_seed0(rank, args.batch)
     t0 = time.time()
     # instance i: seed 1000 + i (the large shape's generator is slow: 64 distinct instances, tiled)
-    batch = P.workload(args.workload, nb, shape, seed0=S.rank_seed0(rank, nb),
+    batch = P.workload(args.workload, nb, shape, seed0=seed0,
                        **({"distinct": 64} if args.shape == "large" else {}))
     log(f"[bench] generated {nb} '{args.workload}' instances per rank in {time.time() - t0:.1f} s")
 
@@ -224,6 +387,9 @@ def main():
     elapsed = S.max_over_ranks(elapsed, red_dev)      # the slowest rank defines the step time
     solved = S.sum_over_ranks(float(nb * args.steps), red_dev)
 
+    if args.warm:
+        # iteration statistics of the TIMED (warm) solves, not of the cold parity solve
+        n_iter = np.asarray(solver.GetSolution().n_iter)
     if rank == 0:
         value = solved / elapsed
         mean_ms = float(np.mean(kernel_ms))
@@ -243,14 +409,17 @@ def main():
             "metric": ("QP solves/sec at batch=4096, walking-log shape" if args.shape == "walking" else
                        "QP solves/sec, 36-DoF / 8-contact shape (BASELINE configs[3], secondary)"),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: FCCQP{tuple(shape.ctor_args)} {args.shape}-shape OSC QPs, "
                             f"{'warm' if args.warm else 'cold'} start, rho={options['rho']:g} "
                             f"eps={options['eps_fcone']:g}/{options['eps_bound']:g} max_iter={options['max_iter']} "
                             f"({'fcc_qp_test.py:78-83' if args.options == 'harness' else 'fccqp.pdf Table 1'})",
-                "batch_per_gpu": nb, "global_batch": nb * world, "parallelism": f"batch-sharded x{world}, no collective",
+                "batch_per_gpu": nb, "global_batch": (args.batch_global if args.scaling == "strong" else nb * world),
+                "parallelism": f"batch-sharded x{world}, no collective",
+                # RCCL carries the two timing barriers and two scalar all-reduces (MAX of elapsed, SUM of solved)
+                "collective_bytes_per_run": 16 if world > 1 else 0,
                 "kernel": {1: "generic", 2: "fused"}[solver.kernel_in_use()], "input_storage": args.inputs,
                 "n_iter_mean": float(n_iter.mean()), "n_iter_at_max_frac": float(np.mean(n_iter == options["max_iter"])),
             },
@@ -266,6 +435,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shape, options, batch, log)
+        if world == 1 and not args.no_extras and args.shape == "walking" and args.workload == "W-sat" \
+                and not args.warm and args.inputs == "f64" and args.options == "harness":
+            from oracle import oracle as O
+            del tens
+            torch.cuda.empty_cache()
+            try:
+                out.update(secondary_measurements(F, P, O, torch, dev, dev_index, log))
+            except Exception as exc:          # the headline line must survive a failing extra
+                out["extras_error"] = repr(exc)
+                log(f"[bench] secondary measurements failed: {exc!r}")
         print(json.dumps(out), flush=True)
 
     if world > 1:

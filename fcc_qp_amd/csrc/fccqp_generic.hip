@@ -1106,6 +1106,34 @@ __device__ __forceinline__ void g_build_mfma_single(lds_f64 *M, const int N, con
   }
 }
 
+// ---- operator iterations of a four-wave workgroup: rho G in the helpers' REGISTERS --------------------------
+// x = x_c + (rho G) w, n <= 128.  The three helper waves each own kMvBlocks blocks of 16 columns of
+// rho G (helper h: blocks kMvBlocks (h - 1) ...), for both row slots (rows lane, 64 + lane): 96
+// doubles per lane, loaded once from the staged G when it is built.  Per iteration a helper reads
+// its share of w as one ds_read_b64 per block (Wq[lane] = w[16 q + (lane & 15)]: every 16-lane row
+// takes a copy) and the FMA fetches its operand from lane l of the row itself (v_fmac_f64 with DPP
+// row_newbcast:l) -- no LDS traffic for G or w inside the product, where the first version streamed
+// its quarter of G (26 KB per wave) and all of w as broadcasts out of LDS on every iteration
+// (2.2 us per iteration at n = 114).  The solver wave only sums the three partial results.
+constexpr int kMvBlocks = 3;                               // 3 helpers x 3 blocks x 16 = 144 >= 128 columns
+constexpr int kMvWLen = 16 * kMvBlocks * 3;                // doubles of w the helpers may read (zero padded)
+template <int IDX>
+__device__ __forceinline__ void dpp_mv_rows(double (&acc)[2][2], const double (&Wq)[kMvBlocks],
+                                            const double (&G)[kMvBlocks][16][2]) {
+  if constexpr (IDX < kMvBlocks * 16) {
+    constexpr int qi = IDX / 16, l = IDX % 16;
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc[0][IDX & 1]) : "v"(Wq[qi]), "v"(G[qi][l][0]), "n"(l));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc[1][IDX & 1]) : "v"(Wq[qi]), "v"(G[qi][l][1]), "n"(l));
+    dpp_mv_rows<IDX + 1>(acc, Wq, G);
+  }
+}
+// where w and the partial sums live once G itself is no longer kept in LDS
+__device__ __forceinline__ bool mv_regs_ok(const int n, const int npack) {
+  return n <= 2 * kWave && g_w_off(n) + kMvWLen + 4 * 2 * kWave <= npack;
+}
+
 // ---- presolve out of the K_rho factorisation ------------------------------------------------------------
 // x0 = (K^-1 [-b; b_eq]).head(n) = (I - rho G)^-1 x_c  (Woodbury on K = K_rho - rho E E^T; derivation and
 // accuracy in fccqp_fused_impl.h, "presolve").  W = I - rho G is symmetric positive definite exactly when
@@ -1127,9 +1155,16 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
   const int n = SHP::fixed ? SHP::n : a.n, N = SHP::fixed ? SHP::n + SHP::m : a.n + a.m;
   lds_f64 *M = (lds_f64 *)lds;
   volatile lds_f64 *ctrl = ctrl_word(lds, N, SHP::fixed ? SHP::nc : a.nc);
+  const bool mv_regs = mv_regs_ok(n, packed_doubles(N));
+  const int qbase = kMvBlocks * (wave - 1);
+  int cmd = 0;
+  bool have_cmd = false;                               // the operator loop below leaves with the next command read
   for (;;) {
-    __syncthreads();                                   // A: a command is posted
-    const int cmd = (int)ctrl[0];
+    if (!have_cmd) {
+      __syncthreads();                                 // A: a command is posted
+      cmd = (int)ctrl[0];
+    }
+    have_cmd = false;
     if (cmd == kCmdDone) break;
     if (cmd == kCmdAssemble) {
       const TIN *Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
@@ -1138,7 +1173,7 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       __syncthreads();                                 // B: the matrix is complete
       continue;
     }
-    if (cmd == kCmdMatvec) {                           // this wave's quarter of x = x_c + (rho G) w
+    if (cmd == kCmdMatvec) {                           // (LDS-resident G) this wave's quarter of the columns
       constexpr int GS = 2;
       double acc0[GS] = {0.0, 0.0}, acc1[GS] = {0.0, 0.0};
       const int nchunk = g_chunks(n), per = (nchunk + WAVES - 1) / WAVES;
@@ -1170,9 +1205,50 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       __syncthreads();                                 // B2: ... it builds W = I - rho G in LDS,
       __syncthreads();                                 // B3: factorises it and solves for x0
     }
-    const int total = n * n;
+    if (mv_regs) {
+      // rho G stays out of LDS: this wave's columns into registers (staged column-major, global / L2).
+      // The array lives in this scope only, and the operator iterations are served from a loop of
+      // their own right here: its live range then holds no call, so it can sit in VGPRs (kept across
+      // the command loop -- which calls the G build and the shared factorisation -- it was parked in
+      // callee-saved AGPRs and every FMA operand cost two v_accvgpr_read).
+      double Greg[kMvBlocks][16][2];                   // rows lane and 64 + lane, columns 16 (qbase + qi) + l
+#pragma unroll
+      for (int qi = 0; qi < kMvBlocks; ++qi) {
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+          const int c = 16 * (qbase + qi) + l;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int row = lane + kWave * t;
+            Greg[qi][l][t] = (c < n && row < n) ? stage[(size_t)c * n + row] : 0.0;
+          }
+        }
+      }
+      __syncthreads();                                 // C: G is in place
+      const lds_f64 *wbuf = M + g_w_off(n);
+      lds_f64 *part = M + g_w_off(n) + kMvWLen;
+      for (;;) {
+        __syncthreads();                               // A
+        cmd = (int)ctrl[0];
+        if (cmd != kCmdMatvec) { have_cmd = true; break; }
+        double Wq[kMvBlocks];
+#pragma unroll
+        for (int qi = 0; qi < kMvBlocks; ++qi) Wq[qi] = wbuf[16 * (qbase + qi) + (lane & 15)];
+        double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        // DPP reads of a VGPR need two wait states after a VALU write of it (see the fused kernel)
+        asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]));
+        dpp_mv_rows<0>(acc, Wq, Greg);
+        part[wave * 2 * kWave + lane] = acc[0][0] + acc[0][1];
+        part[wave * 2 * kWave + kWave + lane] = acc[1][0] + acc[1][1];
+        __syncthreads();                               // B
+      }
+      continue;
+    }
+    {
+      const int total = n * n;
 #pragma unroll 8
-    for (int e = wave * kWave + lane; e < total; e += WAVES * kWave) M[e] = stage[e];
+      for (int e = wave * kWave + lane; e < total; e += WAVES * kWave) M[e] = stage[e];
+    }
     __syncthreads();                                   // C: G is in LDS
   }
 }
@@ -1185,6 +1261,11 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   const int n = SHP::fixed ? SHP::n : a.n, m = SHP::fixed ? SHP::m : a.m, nc = SHP::fixed ? SHP::nc : a.nc,
             s0 = SHP::fixed ? SHP::s : a.s, N = n + m;
   const int npack = packed_doubles(N);
+  // The argument block reaches this function through a pointer (its address is taken for the real
+  // calls), so a.field is a scratch load wherever the compiler cannot prove the copy unchanged -- in
+  // the iteration loop, one per use per iteration.  The scalars of the loop are read once.
+  const double opt_rho = a.rho, opt_eps_bound = a.eps_bound, opt_eps_fcone = a.eps_fcone;
+  const int opt_max_iter = a.max_iter;
 
   // matrix: LDS (ds_* instructions) or the per-block global workspace (global_* instructions)
   using MP = std::conditional_t<MAT_IN_LDS, lds_f64 *, double *>;
@@ -1286,7 +1367,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
                  a.workspace_stride >= (long long)n * n;
   }
   bool use_g = g_possible &&
-               a.max_iter - gswitch >= ((WAVES > 1 || single_mfma) ? kGMinRemainingMulti : kGMinRemaining);
+               opt_max_iter - gswitch >= ((WAVES > 1 || single_mfma) ? kGMinRemainingMulti : kGMinRemaining);
 
   // ---- presolve (fcc_qp.cpp:159-178): skipped on warm start unless equality-only ---------
   // Three ways to x0 = (K^-1 [-b; b_eq]).head(n):
@@ -1356,7 +1437,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
 
   // ---- DoADMM (fcc_qp.cpp:57-112) ----------------------------------------------------------
   if (!equality_constrained) {
-    assemble(a.rho);                                   // :62-64
+    assemble(opt_rho);                                   // :62-64
     const long long t0 = wall_clock64();
     const bool bad = factor(0.0);                      // :68 (info() unchecked in the reference)
     ticks += wall_clock64() - t0;
@@ -1392,38 +1473,53 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     constexpr int RB = g_batch<SLOTS>();
     // LDS doubles after the switch: rho*G [n][n] (column-major) | w [w_len], zero-padded | partial sums
     const int g_off = 0;
-    bool g_ready = false;
+    bool g_ready = false; (void)g_ready;
     const bool coop_mv = (WAVES > 1) && g_part_off(n) + WAVES * 2 * kWave <= npack;
+    const bool mv_regs = (WAVES > 1) && mv_regs_ok(n, npack);     // same predicate as helper_wave
     double xc[GS];
 #pragma unroll
     for (int t = 0; t < GS; ++t) xc[t] = 0.0;
 
-    n_iter = a.max_iter;                               // :78
-    for (int iter = need_w ? -1 : 0; iter < a.max_iter; ++iter) {
-      if constexpr (MAT_IN_LDS && SLOTS <= 4) {
-        if (use_g && !g_ready && (iter == gswitch || iter < 0)) {
+    n_iter = opt_max_iter;                               // :78
+    // The iteration is written as three pieces -- the KKT solve by sweeps, the KKT solve by the
+    // operator, and everything after the solve -- and two loops without a call in them: with the G
+    // build (a real call, ~400 registers) inside the one iteration loop, every value of the solver wave
+    // that did not fit the callee-saved registers lived in scratch and was reloaded from memory in
+    // each iteration (ten scratch loads, ~2 us per iteration on the large shape).
+    bool g_failed = false;                             // W singular: the instance goes to the COD pass
+    int iter = 0;
+    bool done = false;
+    const int first_op = use_g ? (need_w ? 0 : gswitch) : opt_max_iter;   // first iteration on the operator
+    // (no lambdas here: captured by reference, some of the per-lane arrays stayed in scratch memory)
+#pragma nounroll
+    for (int phase = 0; phase < 2 && !done; ++phase) {
+      int iter_end = (first_op < opt_max_iter) ? first_op : opt_max_iter;
+      if (phase == 1) {
+        if (!(use_g && (need_w || iter < opt_max_iter))) break;
+        const bool with_presolve = need_w;
+          if constexpr (MAT_IN_LDS && SLOTS <= 4) {
           double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
           if constexpr (WAVES > 1) {
             if (g_build_mfma_supported(N, n)) {        // [-b; b_eq] where every wave can read it
               lds_f64 *rhs_s = ctrl_word(lds, N, nc) + kCtrlWords;
-#pragma unroll
+    #pragma unroll
               for (int t = 0; t < SLOTS; ++t) {
                 const int i = lane + kWave * t;
                 if (i < N) rhs_s[i] = (i < n) ? -vb[t] : vtail[t];
               }
             }
-            if (lane == 0) { ctrl_word(lds, N, nc)[0] = (double)kCmdBuild; ctrl_word(lds, N, nc)[1] = (iter < 0) ? 1.0 : 0.0; }
+            if (lane == 0) { ctrl_word(lds, N, nc)[0] = (double)kCmdBuild; ctrl_word(lds, N, nc)[1] = with_presolve ? 1.0 : 0.0; }
             __syncthreads();                           // A (see helper_wave)
           }
           bool by_mfma = false;
           if constexpr (WAVES > 1) by_mfma = g_build_mfma_supported(N, n);
           if constexpr (WAVES > 1) {
-            if (by_mfma) g_build_mfma_share<SLOTS>(M, N, n, lane, 0, a.rho, stage, ctrl_word(lds, N, nc) + kCtrlWords);
+            if (by_mfma) g_build_mfma_share<SLOTS>(M, N, n, lane, 0, opt_rho, stage, ctrl_word(lds, N, nc) + kCtrlWords);
           }
           if constexpr (WAVES == 1) {
             if (single_mfma) {
               double *gs = stage + (size_t)n * n;
-#pragma unroll
+    #pragma unroll
               for (int t = 0; t < SLOTS; ++t) {
                 const int i = lane + kWave * t;
                 if (i < N) gs[i] = (i < n) ? -vb[t] : vtail[t];
@@ -1431,14 +1527,14 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
               wave_sync();
-              g_build_mfma_single(M, N, n, lane, a.rho, stage, gs);
+              g_build_mfma_single(M, N, n, lane, opt_rho, stage, gs);
               by_mfma = true;
             }
           }
           if (!by_mfma) {
-            g_build_batch<SLOTS, RB, true>(M, N, n, lane, 0, a.rho, stage, vb, vtail, xc);
+            g_build_batch<SLOTS, RB, true>(M, N, n, lane, 0, opt_rho, stage, vb, vtail, xc);
             for (int b = WAVES; b * RB <= n; b += WAVES)
-              g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
+              g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, opt_rho, stage, nullptr, nullptr, nullptr);
           }
           // the staged columns are read back by other lanes (and waves)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -1448,7 +1544,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
           if constexpr (WAVES > 1) {
             if (by_mfma) {                             // x_c came back through LDS
               const lds_f64 *xc_s = ctrl_word(lds, N, nc) + kCtrlWords + N;
-#pragma unroll
+    #pragma unroll
               for (int t = 0; t < GS; ++t) {
                 const int i = lane + kWave * t;
                 xc[t] = (i < n) ? xc_s[i] : 0.0;
@@ -1457,7 +1553,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
           } else {
             if (by_mfma) {                             // ... or through the staging buffer
               const double *xc_g = stage + (size_t)n * n + N;
-#pragma unroll
+    #pragma unroll
               for (int t = 0; t < GS; ++t) {
                 const int i = lane + kWave * t;
                 xc[t] = (i < n) ? xc_g[i] : 0.0;
@@ -1465,7 +1561,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
             }
           }
           bool wbad = false;
-          if (iter < 0) {
+          if (with_presolve) {
             // presolve: x0 = (I - rho G)^-1 x_c.  W goes over the dead factor in LDS (all waves), this
             // wave factorises it (n x n, one-wave panel code) and solves; G itself is copied in after.
             // (this wave alone: 4 us at n = 114.  With the helpers sharing the columns, the four-slot
@@ -1478,10 +1574,10 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
             wbad = ldlt_factor<GS>(M, n, lane, kPresolveMinPivot);
             ticks += wall_clock64() - tw;
             double xw[GS];
-#pragma unroll
+    #pragma unroll
             for (int t = 0; t < GS; ++t) xw[t] = xc[t];
             ldlt_solve<GS, lds_f64 *>(M, n, lane, xw);
-#pragma unroll
+    #pragma unroll
             for (int t = 0; t < SLOTS; ++t) {
               x[t] = 0.0;
               if (t < GS) x[t] = (lane + kWave * t < n) ? xw[t < GS ? t : 0] : 0.0;
@@ -1490,9 +1586,11 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
             if constexpr (WAVES > 1) __syncthreads();  // B3
             else wave_sync();
           }
-          const int total = n * n;
-#pragma unroll 8
-          for (int e = lane; e < total; e += WAVES * kWave) M[g_off + e] = stage[e];
+          if (!(WAVES > 1 && mv_regs)) {              // (four waves: the helpers keep G in registers)
+            const int total = n * n;
+    #pragma unroll 8
+            for (int e = lane; e < total; e += WAVES * kWave) M[g_off + e] = stage[e];
+          }
           if constexpr (WAVES > 1) __syncthreads();    // C
           else wave_sync();
           g_ready = true;
@@ -1505,117 +1603,134 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
                 a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
                 a.flags[inst] = flags;
               }
-              return;
+              g_failed = true;
             }
           }
-        }
-      }
-      if (iter < 0) continue;
-      if (g_ready) {
-        if constexpr (MAT_IN_LDS && SLOTS <= 4) {
-          lds_f64 *wbuf = M + w_off;
-#pragma unroll
-          for (int t = 0; t < GS; ++t) {
-            const int i = lane + kWave * t;
-            if (i < n) wbuf[i] = is_cone[t] ? (lcbar[t] - mulc[t]) : (xbar[t] - mux[t]);
           }
-          // zero pad (use_g checked the room): padded pairs multiply a clamped, valid column by w = 0
-          const int nchunk = g_chunks(n);
-          for (int i = n + lane; i < w_len; i += kWave) wbuf[i] = 0.0;
-          double acc0[GS], acc1[GS];
-#pragma unroll
-          for (int t = 0; t < GS; ++t) { acc0[t] = xc[t]; acc1[t] = 0.0; }
-          if constexpr (WAVES > 1) {
-            if (coop_mv) {
-              // the four waves take a quarter of the columns each; partial sums meet in LDS
-              const int per = (nchunk + WAVES - 1) / WAVES;
-              if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdMatvec;
-              __syncthreads();                         // A: w is in LDS
-              matvec_range<GS>(M, n, lane, 0, (per < nchunk) ? per : nchunk, acc0, acc1);
-              __syncthreads();                         // B: the helpers' partial sums are in LDS
-              const lds_f64 *part = M + g_part_off(n);
-#pragma unroll
-              for (int w = 1; w < WAVES; ++w) {
-#pragma unroll
-                for (int t = 0; t < GS; ++t) acc0[t] += part[w * 2 * kWave + lane + kWave * t];
+
+        if (g_failed) return;
+        iter_end = opt_max_iter;
+      }
+#pragma nounroll
+      for (; iter < iter_end; ++iter) {
+        if (phase == 1) {
+            if constexpr (MAT_IN_LDS && SLOTS <= 4) {
+            lds_f64 *wbuf = M + w_off;
+      #pragma unroll
+            for (int t = 0; t < GS; ++t) {
+              const int i = lane + kWave * t;
+              if (i < n) wbuf[i] = is_cone[t] ? (lcbar[t] - mulc[t]) : (xbar[t] - mux[t]);
+            }
+            // zero pad (use_g checked the room): padded pairs multiply a clamped, valid column by w = 0
+            const int nchunk = g_chunks(n);
+            const int wpad = mv_regs ? kMvWLen : w_len;
+            for (int i = n + lane; i < wpad; i += kWave) wbuf[i] = 0.0;
+            double acc0[GS], acc1[GS];
+      #pragma unroll
+            for (int t = 0; t < GS; ++t) { acc0[t] = xc[t]; acc1[t] = 0.0; }
+            if constexpr (WAVES > 1) {
+              if (mv_regs) {
+                // the helpers hold rho G in registers (helper_wave): post w, collect three partial sums
+                if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdMatvec;
+                __syncthreads();                         // A: w is in LDS
+                __syncthreads();                         // B: the helpers' partial sums are in LDS
+                const lds_f64 *part = M + w_off + kMvWLen;
+      #pragma unroll
+                for (int w = 1; w < WAVES; ++w) {
+      #pragma unroll
+                  for (int t = 0; t < GS; ++t) acc0[t] += part[w * 2 * kWave + lane + kWave * t];
+                }
+              } else if (coop_mv) {
+                // the four waves take a quarter of the columns each; partial sums meet in LDS
+                const int per = (nchunk + WAVES - 1) / WAVES;
+                if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdMatvec;
+                __syncthreads();                         // A: w is in LDS
+                matvec_range<GS>(M, n, lane, 0, (per < nchunk) ? per : nchunk, acc0, acc1);
+                __syncthreads();                         // B: the helpers' partial sums are in LDS
+                const lds_f64 *part = M + g_part_off(n);
+      #pragma unroll
+                for (int w = 1; w < WAVES; ++w) {
+      #pragma unroll
+                  for (int t = 0; t < GS; ++t) acc0[t] += part[w * 2 * kWave + lane + kWave * t];
+                }
+              } else {
+                wave_sync();
+                matvec_range<GS>(M, n, lane, 0, nchunk, acc0, acc1);
               }
             } else {
               wave_sync();
               matvec_range<GS>(M, n, lane, 0, nchunk, acc0, acc1);
             }
-          } else {
-            wave_sync();
-            matvec_range<GS>(M, n, lane, 0, nchunk, acc0, acc1);
-          }
-#pragma unroll
-          for (int t = 0; t < SLOTS; ++t) x[t] = 0.0;
-#pragma unroll
-          for (int t = 0; t < GS; ++t) {
-            const int i = lane + kWave * t;
-            x[t] = (i < n) ? acc0[t] + acc1[t] : 0.0;
-          }
+      #pragma unroll
+            for (int t = 0; t < SLOTS; ++t) x[t] = 0.0;
+      #pragma unroll
+            for (int t = 0; t < GS; ++t) {
+              const int i = lane + kWave * t;
+              x[t] = (i < n) ? acc0[t] + acc1[t] : 0.0;
+            }
+            }
+
+        } else {
+            double r[SLOTS];
+      #pragma unroll
+            for (int t = 0; t < SLOTS; ++t) {
+              const int i = lane + kWave * t;
+              double q = -opt_rho * (xbar[t] - mux[t]);                    // :81
+              if (is_cone[t]) q = -opt_rho * (lcbar[t] - mulc[t]);          // :82 overwrites the segment
+              r[t] = (i < n) ? -(vb[t] + q) : vtail[t];                   // :83
+            }
+            ldlt_solve<SLOTS, MP>(M, N, lane, r);                             // :86
+      #pragma unroll
+            for (int t = 0; t < SLOTS; ++t) {
+              const int i = lane + kWave * t;
+              x[t] = (i < n) ? r[t] : 0.0;                                // :87
+            }
+
         }
-      } else {
-        double r[SLOTS];
-#pragma unroll
+        // slack update :90-92
+        wave_sync();
+  #pragma unroll
         for (int t = 0; t < SLOTS; ++t) {
           const int i = lane + kWave * t;
-          double q = -a.rho * (xbar[t] - mux[t]);                    // :81
-          if (is_cone[t]) q = -a.rho * (lcbar[t] - mulc[t]);          // :82 overwrites the segment
-          r[t] = (i < n) ? -(vb[t] + q) : vtail[t];                   // :83
+          if (is_cone[t]) cone_buf[i - s0] = x[t] + mulc[t];
         }
-        ldlt_solve<SLOTS, MP>(M, N, lane, r);                             // :86
-#pragma unroll
+        wave_sync();
+  #pragma unroll
         for (int t = 0; t < SLOTS; ++t) {
           const int i = lane + kWave * t;
-          x[t] = (i < n) ? r[t] : 0.0;                                // :87
+          xr_last[t] = 0.0; lr_last[t] = 0.0;
+          if (i < n) {
+            const double v = x[t] + mux[t];
+            const double tt = (vub[t] < v) ? vub[t] : v;   // std::min(x, ub)
+            xbar[t] = (tt < vlb[t]) ? vlb[t] : tt;         // std::max(., lb)  constraint_utils.cpp:43
+            xr_last[t] = x[t] - xbar[t];                    // :95
+            mux[t] += xr_last[t];                           // :101
+          }
+          if (is_cone[t]) {
+            const int base = 3 * cidx[t];
+            lcbar[t] = project_cone_component(cone_buf[base], cone_buf[base + 1], cone_buf[base + 2], vmu[t], vkc[t],
+                                              x[t] + mulc[t], ccomp[t] == 2);
+            lr_last[t] = x[t] - lcbar[t];                   // :96
+            mulc[t] += lr_last[t];                          // :102
+          }
         }
-      }
-      // slack update :90-92
-      wave_sync();
-#pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int i = lane + kWave * t;
-        if (is_cone[t]) cone_buf[i - s0] = x[t] + mulc[t];
-      }
-      wave_sync();
-#pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int i = lane + kWave * t;
-        xr_last[t] = 0.0; lr_last[t] = 0.0;
-        if (i < n) {
-          const double v = x[t] + mux[t];
-          const double tt = (vub[t] < v) ? vub[t] : v;   // std::min(x, ub)
-          xbar[t] = (tt < vlb[t]) ? vlb[t] : tt;         // std::max(., lb)  constraint_utils.cpp:43
-          xr_last[t] = x[t] - xbar[t];                    // :95
-          mux[t] += xr_last[t];                           // :101
+        // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps: one ballot per iteration
+        // instead of four wave reductions; the norms themselves (:97-98) are only reported and are
+        // reduced once after the loop.  An empty contact set has norm 0.
+        bool ok = true;
+  #pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+          const int i = lane + kWave * t;
+          if (i < n) ok = ok && (fabs(xr_last[t]) < opt_eps_bound);
+          if (is_cone[t]) ok = ok && (fabs(lr_last[t]) < opt_eps_fcone);
         }
-        if (is_cone[t]) {
-          const int base = 3 * cidx[t];
-          lcbar[t] = project_cone_component(cone_buf[base], cone_buf[base + 1], cone_buf[base + 2], vmu[t], vkc[t],
-                                            x[t] + mulc[t], ccomp[t] == 2);
-          lr_last[t] = x[t] - lcbar[t];                   // :96
-          mulc[t] += lr_last[t];                          // :102
-        }
-      }
-      // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps: one ballot per iteration
-      // instead of four wave reductions; the norms themselves (:97-98) are only reported and are
-      // reduced once after the loop.  An empty contact set has norm 0.
-      bool ok = true;
-#pragma unroll
-      for (int t = 0; t < SLOTS; ++t) {
-        const int i = lane + kWave * t;
-        if (i < n) ok = ok && (fabs(xr_last[t]) < a.eps_bound);
-        if (is_cone[t]) ok = ok && (fabs(lr_last[t]) < a.eps_fcone);
-      }
-      if (nc == 0) ok = ok && (0.0 < a.eps_fcone);
-      if (n == 0) ok = ok && (0.0 < a.eps_bound);
-      if (__all(ok)) {
-        n_iter = iter;
-        break;
+        if (nc == 0) ok = ok && (0.0 < opt_eps_fcone);
+        if (n == 0) ok = ok && (0.0 < opt_eps_bound);
+
+        if (__all(ok)) { n_iter = iter; done = true; break; }
       }
     }
-    if (a.max_iter > 0) {
+    if (opt_max_iter > 0) {
       // :97-98  abs(max(maxCoeff, -minCoeff)) == max_i |r_i| of the last iteration executed
       double xm = 0.0, lm = 0.0;
 #pragma unroll

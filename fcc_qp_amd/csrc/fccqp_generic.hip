@@ -1202,8 +1202,10 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
     __syncthreads();                                   // B: every column of G is staged, L is dead
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if ((double)ctrl[1] != 0.0) {                      // the solver wave wants x0 out of G first:
-      __syncthreads();                                 // B2: ... it builds W = I - rho G in LDS,
-      __syncthreads();                                 // B3: factorises it and solves for x0
+      __syncthreads();                                 // B2: ... it has built W = I - rho G in LDS;
+      const bool wb = ldlt_factor_share<(SLOTS < 2 ? SLOTS : 2)>(M, n, lane, wave, WAVES, ctrl + 2, kPresolveMinPivot);
+      if (lane == 0) ctrl[3 + wave] = wb ? 1.0 : 0.0;  // the n x n factorisation is shared like the KKT one
+      __syncthreads();                                 // B3: W is factorised (the solver wave solves alone)
     }
     if (mv_regs) {
       // rho G stays out of LDS: this wave's columns into registers (staged column-major, global / L2).
@@ -1381,10 +1383,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     flags |= kFlagPresolveRan | kFlagPresolveNumerical | kFlagPresolveCod;
   } else if (equality_constrained || !a.warm_start) {
     flags |= kFlagPresolveRan;
-    // (w) first only in one-wave workgroups: with four waves the K factorisation is shared by the
-    // waves (72 us at N = 174) while W is factorised by this wave alone (70 us at n = 114) -- measured
-    // 438 k vs 453 k solves/s on the large shape; there (w) is the second chance after (d)
-    if (!equality_constrained && use_g && WAVES == 1) {
+    if (!equality_constrained && use_g) {
       need_w = true;                                   // (w)
     } else {
       // breakdown threshold of the unpivoted presolve (see ldlt_panel): 16 N eps max_i |Q_ii|
@@ -1562,16 +1561,24 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
           }
           bool wbad = false;
           if (with_presolve) {
-            // presolve: x0 = (I - rho G)^-1 x_c.  W goes over the dead factor in LDS (all waves), this
-            // wave factorises it (n x n, one-wave panel code) and solves; G itself is copied in after.
-            // (this wave alone: 4 us at n = 114.  With the helpers sharing the columns, the four-slot
-            // kernel -- and only that instantiation -- hung or faulted in their copy of the loop;
-            // their code is left exactly as it is without the presolve)
+            // presolve: x0 = (I - rho G)^-1 x_c.  W goes over the dead factor in LDS (this wave alone:
+            // 4 us at n = 114), its n x n factorisation is shared by the waves like the KKT one, this
+            // wave solves.
             presolve_w_share(M, stage, n, lane, 0, 1);
-            if constexpr (WAVES > 1) __syncthreads();  // B2
-            else wave_sync();
             const long long tw = wall_clock64();
-            wbad = ldlt_factor<GS>(M, n, lane, kPresolveMinPivot);
+            if constexpr (WAVES > 1) {
+              volatile lds_f64 *ctrl = ctrl_word(lds, N, nc);
+              if (lane == 0) ctrl[2] = 0.0;          // finished-panel count of the shared factorisation
+              __syncthreads();                       // B2
+              const bool mine = ldlt_factor_share<GS>(M, n, lane, 0, WAVES, ctrl + 2, kPresolveMinPivot);
+              if (lane == 0) ctrl[3] = mine ? 1.0 : 0.0;
+              __syncthreads();                       // B3
+#pragma unroll
+              for (int w = 0; w < WAVES; ++w) wbad = wbad || (ctrl[3 + w] != 0.0);
+            } else {
+              wave_sync();
+              wbad = ldlt_factor<GS>(M, n, lane, kPresolveMinPivot);
+            }
             ticks += wall_clock64() - tw;
             double xw[GS];
     #pragma unroll
@@ -1583,8 +1590,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               if (t < GS) x[t] = (lane + kWave * t < n) ? xw[t < GS ? t : 0] : 0.0;
               xbar[t] = x[t]; lcbar[t] = x[t];           // :74-75
             }
-            if constexpr (WAVES > 1) __syncthreads();  // B3
-            else wave_sync();
+            wave_sync();
           }
           if (!(WAVES > 1 && mv_regs)) {              // (four waves: the helpers keep G in registers)
             const int total = n * n;

@@ -399,9 +399,9 @@ def main():
         tr_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tr_path):
             try:
-                tr = json.load(open(tr_path))
+                tr = json.load(open(tr_path)).get(args.shape, {})     # rocprofv3 PMC passes, tools/parse_profile.py
                 if tr.get("batch") == nb and tr.get("workload") == args.workload and tr.get("kernel") == solver.kernel_in_use() \
-                        and args.shape == "walking" and args.inputs == "f64" and not args.warm:
+                        and args.inputs == "f64" and not args.warm and args.options == "harness":
                     traffic = tr.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -48,7 +48,10 @@ struct fccqp_solver {
   unsigned solve_seq = 0;
   double *dcod_ws = nullptr;
   long long cod_stride = 0;
-  static constexpr int kFallbackBlocks = 64;
+  // persistent one-wave workgroups of the fallback launch (list mode).  Round 1 used 64 whatever the
+  // batch: a batch whose instances all need the COD pass ran on 64 of the 1024 wave slots.  Now one
+  // per instance up to a full grid, bounded by 256 MiB of COD workspace (2 N^2 doubles per block).
+  int fb_blocks = 1;
   long long work_stride = 0;
   std::string err;
 };
@@ -183,7 +186,7 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   if (fb) {
     // fallback launch over the (normally empty) device list: COD x0, then ADMM from it.  It also
     // zeroes the other counter, which the next solve's main kernel will append to.
-    const int blocks = fccqp_solver::kFallbackBlocks < s->batch ? fccqp_solver::kFallbackBlocks : s->batch;
+    const int blocks = s->fb_blocks;
     fccqp::KernelArgs b = a;
     b.fb_list = nullptr; b.fb_count = nullptr;
     b.inst_list = s->dfb_list; b.inst_count = cnt; b.next_count = cnt_next;
@@ -292,7 +295,13 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
     HIP_TRY(s, dmalloc(&s->dfb_count, 2));
     HIP_TRY(s, hipMemset(s->dfb_count, 0, 2 * sizeof(int)));
     s->cod_stride = fccqp::cod_workspace_doubles_host(num_vars, num_equality_constraints);
-    HIP_TRY(s, dmalloc(&s->dcod_ws, (size_t)fccqp_solver::kFallbackBlocks * (size_t)s->cod_stride));
+    {
+      long long blocks = batch < 1024 ? batch : 1024;
+      const long long fit = (256ll << 20) / (8 * (s->cod_stride > 0 ? s->cod_stride : 1));
+      if (blocks > fit) blocks = fit;
+      s->fb_blocks = (int)(blocks < 1 ? 1 : blocks);
+    }
+    HIP_TRY(s, dmalloc(&s->dcod_ws, (size_t)s->fb_blocks * (size_t)s->cod_stride));
     return FCCQP_OK;
   }();
   if (rc != FCCQP_OK) {

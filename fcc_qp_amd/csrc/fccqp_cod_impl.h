@@ -14,8 +14,10 @@
 // x = P Z^T [T^-1 (Q^T b)_1 ; 0]) -- the same steps as the oracle's restatement
 // (oracle/fccqp_oracle.c: fccqp_oracle_cod_solve), with the sums done as wave reductions.
 //
-// This is a rare path (exactly singular cost blocks): one wavefront per listed instance, matrix in
-// a global-memory workspace (L2-resident), written for clarity, not speed.
+// This is a rare path (K singular to working precision): one wavefront per listed instance, written
+// for clarity.  The two N x N work matrices live in LDS when they fit (N <= 98: the walking shape,
+// 158 KB, one workgroup per CU) -- in a global workspace the QR is bound by uncoalesced L2 traffic
+// (one column per lane) and an all-singular batch of 4096 took 224 ms whatever the grid size.
 #pragma once
 #include <cfloat>
 
@@ -39,15 +41,19 @@ __device__ __forceinline__ double wmax(double v) {
   }
   return v;
 }
+// LDSW: the workspace is in LDS (in-order for one wave: the fence only pins the compiler); otherwise it
+// is global memory, through which the lanes exchange data: agent scope (see global_phase_sync in
+// fccqp_generic.hip for why the wavefront-scope fence is not relied on there)
+template <bool LDSW>
 __device__ __forceinline__ void wsync() {
-  // agent scope: the lanes exchange data through the global workspace (see global_phase_sync in
-  // fccqp_generic.hip for why the wavefront-scope fence is not relied on)
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  if constexpr (LDSW) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
   __builtin_amdgcn_wave_barrier();
 }
 
 // Householder vector for x[0..len): returns tau, x[0] := beta, x[1..] := essential part.
 // (same conventions as make_householder in the oracle)
+template <bool LDSW>
 __device__ double householder(double *x, int len, int lane) {
   double part = 0.0;
   for (int i = 1 + lane; i < len; i += kWave) part += x[i] * x[i];
@@ -55,32 +61,33 @@ __device__ double householder(double *x, int len, int lane) {
   const double c0 = x[0];
   if (tail_sq <= DBL_MIN) {
     for (int i = 1 + lane; i < len; i += kWave) x[i] = 0.0;
-    wsync();
+    wsync<LDSW>();
     return 0.0;
   }
   double beta = sqrt(c0 * c0 + tail_sq);
   if (c0 >= 0.0) beta = -beta;
   const double den = c0 - beta;
   for (int i = 1 + lane; i < len; i += kWave) x[i] /= den;
-  wsync();
+  wsync<LDSW>();
   if (lane == 0) x[0] = beta;
-  wsync();
+  wsync<LDSW>();
   return (beta - c0) / beta;
 }
 
 // y[0..len) -= tau * v (v^T y) with v = [1; vess[1..len)]   (one target vector, wave-parallel)
+template <bool LDSW>
 __device__ void apply_reflector(const double *vess, double tau, double *y, int len, int lane) {
   double part = (lane == 0) ? y[0] : 0.0;
   for (int i = 1 + lane; i < len; i += kWave) part += vess[i] * y[i];
   const double s = wsum(part) * tau;
   if (lane == 0) y[0] -= s;
   for (int i = 1 + lane; i < len; i += kWave) y[i] -= s * vess[i];
-  wsync();
+  wsync<LDSW>();
 }
 
 // Minimum-norm least-squares x0 of instance `inst` into a.x; W = this block's workspace
 // (cod_workspace_doubles(n, m) doubles).
-template <class TIN>
+template <class TIN, bool LDSW>
 __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
   const int lane = threadIdx.x;
   const int n = a.n, m = a.m, N = n + m;
@@ -114,7 +121,7 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
       perm[i] = i;
       tau[i] = 0.0;
     }
-    wsync();
+    wsync<LDSW>();
 
     // ---- column-pivoted Householder QR, c := Q^T rhs on the fly --------------------------------
     double maxpivot = 0.0;
@@ -141,11 +148,11 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
           A[i + (size_t)besti * N] = t;
         }
         if (lane == 0) { const int t = perm[k]; perm[k] = perm[besti]; perm[besti] = t; }
-        wsync();
+        wsync<LDSW>();
       }
       double *col = A + k + (size_t)k * N;
       const int len = N - k;
-      const double tk = householder(col, len, lane);
+      const double tk = householder<LDSW>(col, len, lane);
       if (lane == 0) tau[k] = tk;
       const double beta = col[0];
       if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
@@ -159,10 +166,10 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
           cj[0] -= s;
           for (int i = 1; i < len; ++i) cj[i] -= s * col[i];
         }
-        wsync();
-        apply_reflector(col, tk, c + k, len, lane);
+        wsync<LDSW>();
+        apply_reflector<LDSW>(col, tk, c + k, len, lane);
       }
-      wsync();
+      wsync<LDSW>();
     }
     const double thresh = DBL_EPSILON * (double)N * maxpivot;
     int rank = 0;
@@ -170,17 +177,17 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
       if (fabs(A[k + (size_t)k * N]) > thresh) ++rank;   // uniform: every lane counts the same
 
     for (int i = lane; i < N; i += kWave) y[i] = 0.0;
-    wsync();
+    wsync<LDSW>();
     if (rank == N) {
       // back substitution R y = c (column oriented)
       for (int i = lane; i < N; i += kWave) w[i] = c[i];
-      wsync();
+      wsync<LDSW>();
       for (int k = N - 1; k >= 0; --k) {
         const double yk = w[k] / A[k + (size_t)k * N];
-        wsync();
+        wsync<LDSW>();
         if (lane == 0) y[k] = yk;
         for (int i = lane; i < k; i += kWave) w[i] -= A[i + (size_t)k * N] * yk;
-        wsync();
+        wsync<LDSW>();
       }
     } else if (rank > 0) {
       const int r = rank;
@@ -190,11 +197,11 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
         B[i + (size_t)j * N] = (i >= j) ? A[j + (size_t)i * N] : 0.0;
       }
       for (int i = lane; i < N; i += kWave) tz[i] = 0.0;
-      wsync();
+      wsync<LDSW>();
       for (int k = 0; k < r; ++k) {
         double *col = B + k + (size_t)k * N;
         const int len = N - k;
-        const double tk = householder(col, len, lane);
+        const double tk = householder<LDSW>(col, len, lane);
         if (lane == 0) tz[k] = tk;
         if (tk != 0.0) {
           for (int j = k + 1 + lane; j < r; j += kWave) {
@@ -206,26 +213,26 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
             for (int i = 1; i < len; ++i) cj[i] -= s * col[i];
           }
         }
-        wsync();
+        wsync<LDSW>();
       }
       // Tt is upper r x r in B; solve Tt^T u = c1 by forward substitution (sequential in i)
       for (int i = lane; i < N; i += kWave) w[i] = 0.0;
-      wsync();
+      wsync<LDSW>();
       for (int i = 0; i < r; ++i) {
         double part = 0.0;
         for (int j = lane; j < i; j += kWave) part += B[j + (size_t)i * N] * w[j];
         const double s = c[i] - wsum(part);
-        wsync();
+        wsync<LDSW>();
         if (lane == 0) w[i] = s / B[i + (size_t)i * N];
-        wsync();
+        wsync<LDSW>();
       }
       // y = Zt [u; 0] = H_0 ... H_{r-1} [u; 0]
       for (int k = r - 1; k >= 0; --k) {
         const double tk = tz[k];
-        if (tk != 0.0) apply_reflector(B + k + (size_t)k * N, tk, w + k, N - k, lane);
+        if (tk != 0.0) apply_reflector<LDSW>(B + k + (size_t)k * N, tk, w + k, N - k, lane);
       }
       for (int i = lane; i < N; i += kWave) y[i] = w[i];
-      wsync();
+      wsync<LDSW>();
     }
     // x[perm[j]] = y[j]; only the first n entries are the solution x_ (fcc_qp.cpp:176)
     double *xs = a.x + (size_t)inst * n;
@@ -233,7 +240,7 @@ __device__ void cod_presolve(const KernelArgs &a, const int inst, double *W) {
       const int p = perm[j];
       if (p < n) xs[p] = y[j];
     }
-    wsync();
+    wsync<LDSW>();
   }
 }
 

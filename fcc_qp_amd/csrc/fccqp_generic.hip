@@ -1804,7 +1804,12 @@ __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void gene
   // wave 0 runs the solver (all of it when WAVES == 1); see helper_wave for the others
   auto run = [&](const int inst, const bool from_list) {
     if (wave == 0) {
-      if (from_list) cod::cod_presolve<TIN>(a, inst, a.cod_ws + (long long)blockIdx.x * a.cod_stride);   // fcc_qp.cpp:165,176
+      if (from_list) {                                   // fcc_qp.cpp:165,176
+        // cod_stride < 0: the list launch was given enough LDS for the COD's work matrices (they are
+        // dead before solve_instance lays the packed KKT over them)
+        if (a.cod_stride < 0) cod::cod_presolve<TIN, true>(a, inst, (double *)lds);
+        else cod::cod_presolve<TIN, false>(a, inst, a.cod_ws + (long long)blockIdx.x * a.cod_stride);
+      }
       solve_instance<SLOTS, MAT_IN_LDS, TIN, SHP>(a, lds, inst, from_list);
       if constexpr (WAVES > 1) {
         if (lane == 0) ctrl_word(lds, SHP::fixed ? SHP::n + SHP::m : a.n + a.m, SHP::fixed ? SHP::nc : a.nc)[0] = (double)kCmdDone;
@@ -1893,12 +1898,21 @@ long long generic_workspace_doubles(int n, int m, int nc, size_t lds_limit) {
 }
 
 template <class TIN>
-static hipError_t launch_generic_blocks(const KernelArgs &a, size_t lds_limit, int blocks, hipStream_t stream) {
+static hipError_t launch_generic_blocks(const KernelArgs &a_in, size_t lds_limit, int blocks, hipStream_t stream) {
+  KernelArgs a = a_in;
   const int N = a.n + a.m;
   if (N > kGenericMaxN) return hipErrorInvalidValue;
   if (a.batch <= 0 || blocks <= 0) return hipSuccess;
   const bool in_lds = generic_lds_bytes(a.n, a.m, a.nc) <= lds_limit;
-  const size_t lds = in_lds ? generic_lds_bytes(a.n, a.m, a.nc) : sizeof(double) * ((size_t)a.nc + 2);
+  size_t lds = in_lds ? generic_lds_bytes(a.n, a.m, a.nc) : sizeof(double) * ((size_t)a.nc + 2);
+  if (a.inst_list && in_lds && N <= 2 * kWave) {
+    // list mode (COD pass) of a one-wave shape: the COD's work matrices in LDS if they fit
+    const size_t cod_bytes = sizeof(double) * (size_t)cod_workspace_doubles(a.n, a.m);
+    if (cod_bytes <= lds_limit) {
+      if (cod_bytes > lds) lds = cod_bytes;
+      a.cod_stride = -1;
+    }
+  }
   const int slots = slots_for(N > 0 ? N : 1);
   switch (slots) {
     case 1: return launch_slots<1, TIN>(a, in_lds, lds, blocks, stream);

@@ -1140,11 +1140,34 @@ __device__ __forceinline__ bool mv_regs_ok(const int n, const int npack) {
 // K is non-singular, with eigenvalues in (0, 1]; a pivot <= kPresolveMinPivot sends the instance to the
 // COD fallback.  This wave's share of W, packed lower, from the staged rho G (column-major, global):
 constexpr double kPresolveMinPivot = 1e-10;
+// (lane = row, 16 columns per trip with all their loads issued before the first store: one load in
+// flight per trip made this 70 us at n = 114 -- 228 dependent L2 round trips)
 __device__ __forceinline__ void presolve_w_share(lds_f64 *M, const double *stage, const int n, const int lane,
                                                  const int part, const int parts) {
-  for (int j = part; j < n; j += parts) {
-    const int cj = col_base(j, n);
-    for (int i = j + lane; i < n; i += kWave) M[cj + i] = ((i == j) ? 1.0 : 0.0) - stage[(size_t)j * n + i];
+  constexpr int CB = 16;
+  for (int j0 = CB * part; j0 < n; j0 += CB * parts) {
+    double v[CB][2];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      const int j = (j0 + u < n) ? j0 + u : n - 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = lane + kWave * t;
+        v[u][t] = (i < n && i >= j) ? stage[(size_t)j * n + i] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      const int j = j0 + u;
+      if (j < n) {
+        const int cj = col_base(j, n);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int i = lane + kWave * t;
+          if (i < n && i >= j) M[cj + i] = ((i == j) ? 1.0 : 0.0) - v[u][t];
+        }
+      }
+    }
   }
 }
 
@@ -1268,6 +1291,10 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   // the iteration loop, one per use per iteration.  The scalars of the loop are read once.
   const double opt_rho = a.rho, opt_eps_bound = a.eps_bound, opt_eps_fcone = a.eps_fcone;
   const int opt_max_iter = a.max_iter;
+  // optional phase stamps (fccqp_phase_seconds): [0] up to the end of the K_rho assembly (incl. a direct
+  // presolve), [1] factorisations, [3] operator build incl. the presolve out of G ([2] of it), [4] iterations
+  const long long ph_begin = wall_clock64();
+  long long ph_asm_end = ph_begin, ph_build = 0, ph_presolve = 0, ph_iter_begin = ph_begin;
 
   // matrix: LDS (ds_* instructions) or the per-block global workspace (global_* instructions)
   using MP = std::conditional_t<MAT_IN_LDS, lds_f64 *, double *>;
@@ -1438,8 +1465,10 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
   if (!equality_constrained) {
     assemble(opt_rho);                                   // :62-64
     const long long t0 = wall_clock64();
+    ph_asm_end = t0;
     const bool bad = factor(0.0);                      // :68 (info() unchecked in the reference)
     ticks += wall_clock64() - t0;
+    ph_iter_begin = wall_clock64();
     if (bad) flags |= kFlagAdmmNumerical;
 
     double xbar[SLOTS], lcbar[SLOTS];
@@ -1496,6 +1525,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
       if (phase == 1) {
         if (!(use_g && (need_w || iter < opt_max_iter))) break;
         const bool with_presolve = need_w;
+        const long long tb0 = wall_clock64();
           if constexpr (MAT_IN_LDS && SLOTS <= 4) {
           double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
           if constexpr (WAVES > 1) {
@@ -1580,6 +1610,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               wbad = ldlt_factor<GS>(M, n, lane, kPresolveMinPivot);
             }
             ticks += wall_clock64() - tw;
+            ph_presolve = wall_clock64() - tw;
             double xw[GS];
     #pragma unroll
             for (int t = 0; t < GS; ++t) xw[t] = xc[t];
@@ -1615,6 +1646,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
           }
 
         if (g_failed) return;
+        ph_build = wall_clock64() - tb0;
         iter_end = opt_max_iter;
       }
 #pragma nounroll
@@ -1793,6 +1825,18 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     a.metrics[2 * (size_t)a.batch + inst] = bv;
     a.metrics[3 * (size_t)a.batch + inst] = cv;
     a.factor_ticks[inst] = ticks;
+    if (a.phase_ticks) {
+      const size_t B = (size_t)a.batch;
+      const long long t_end = wall_clock64();
+      a.phase_ticks[0 * B + inst] = ph_asm_end - ph_begin;
+      a.phase_ticks[1 * B + inst] = ticks;
+      a.phase_ticks[2 * B + inst] = ph_presolve;
+      a.phase_ticks[3 * B + inst] = ph_build;
+      a.phase_ticks[4 * B + inst] = (t_end - ph_iter_begin) - ph_build;
+      a.phase_ticks[5 * B + inst] = t_end - ph_begin;
+      a.phase_ticks[6 * B + inst] = 0;
+      a.phase_ticks[7 * B + inst] = ph_begin;
+    }
   }
 }
 

@@ -720,15 +720,18 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
   }
 }
 
-// acc[j % 4] += Wq[j / 16](lane j % 16 of this lane's 16-lane row) * Mrow[j], j = J .. NN-1: the mat-vec of
-// an ADMM iteration with the vector operand fetched by the FMA itself (DPP row_newbcast); four
-// accumulators break the FMA dependency chain.  (A recursive template, not a lambda: clang does not
-// capture variables that a generic lambda only names in asm operands.)
+// acc[j % kMvAcc] += Wq[j / 16](lane j % 16 of this lane's 16-lane row) * Mrow[j], j = J .. NN-1: the mat-vec of
+// an ADMM iteration with the vector operand fetched by the FMA itself (DPP row_newbcast); several
+// accumulators break the FMA dependency chain -- kMvAcc = 6 of them: a DPP instruction that reads a VGPR
+// a VALU instruction wrote fewer than five instructions earlier gets an s_nop from the hazard
+// recogniser (with four accumulators: one s_nop per four FMAs).  (A recursive template, not a lambda:
+// clang does not capture variables that a generic lambda only names in asm operands.)
+constexpr int kMvAcc = 6;
 template <int J, int NN, int NQ>
-__device__ __forceinline__ void dpp_matvec(double (&acc)[4], const double (&Wq)[NQ], const double (&Mrow)[NN]) {
+__device__ __forceinline__ void dpp_matvec(double (&acc)[kMvAcc], const double (&Wq)[NQ], const double (&Mrow)[NN]) {
   if constexpr (J < NN) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc[J % 4]) : "v"(Wq[J / 16]), "v"(Mrow[J]), "n"(J % 16));
+        : "+v"(acc[J % kMvAcc]) : "v"(Wq[J / 16]), "v"(Mrow[J]), "n"(J % 16));
     dpp_matvec<J + 1, NN, NQ>(acc, Wq, Mrow);
   }
 }
@@ -844,9 +847,13 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   // [-b; b_eq] (fcc_qp.cpp:149-150) into vbuf[0..N)
   auto stage_rhs = [&]() {
     const double *bp = fresh(bq), *ep = fresh(beq);
-    vbuf[lane] = isvar ? -bp[lane] : 0.0;
+    // both loads before the first LDS store: with the fence between them they were two dependent
+    // HBM round trips
+    const double vb = isvar ? -bp[lane] : 0.0;
+    const double ve = (lane < m) ? ep[lane < m ? lane : 0] : 0.0;
+    vbuf[lane] = vb;
     lds_fence();
-    if (lane < m) vbuf[n + lane] = ep[lane];  // n + lane < N <= kVbuf
+    if (lane < m) vbuf[n + lane] = ve;        // n + lane < N <= kVbuf
     lds_fence();
   };
 
@@ -966,7 +973,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];   // entries >= n were written as 0
       lds_fence();
-      double acc[4] = {xc, 0.0, 0.0, 0.0};
+      double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0, 0.0, 0.0};
       // the DPP read of a VGPR needs two wait states after a VALU write of it (the registers come
       // straight from the LDS reads, but a copy could be scheduled in between): pin them here
       if constexpr (NQ == 4) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]), "+v"(Wq[3]));
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       else if constexpr (NQ == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
       else asm volatile("s_nop 1" : "+v"(Wq[0]));
       dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
-      const double acc0 = acc[0], acc1 = acc[1], acc2 = acc[2], acc3 = acc[3];
+      const double acc0 = acc[0] + acc[4], acc1 = acc[1] + acc[5], acc2 = acc[2], acc3 = acc[3];
       x = (acc0 + acc1) + (acc2 + acc3);
       lds_fence();
       // slack update :90-92

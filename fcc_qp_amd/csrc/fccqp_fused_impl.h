@@ -419,68 +419,57 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) X[I][cb] = T[cb];
   }
-  // ---- D^-1 (diagonal slots hold 1/d with the pseudo-inverse rule folded in) --------------------------
+  // ---- G = Y^T D^-1 Y with Y = L^-1 [E | r] (the forward result) -------------------------------------
+  // (K_rho^-1)[0:n, 0:n] = E^T L^-T D^-1 L^-1 E: instead of the backward sweep with L^T -- 364 MFMAs
+  // chained through the row blocks, each with an operand out of LDS -- the product of the forward
+  // result with itself: register r of tile Y[K][cb] is at once the B operand (B[k][n] = Y[4r+k][n])
+  // and, for the transposed factor, the A operand (A[i][k] = Y[4r+k][i]) of k-step r, so all
+  // operands come out of the accumulators, the tile products are independent of each other, only
+  // the lower tiles (J <= I) are computed and Y's zero tiles (rows above the unit entries) are
+  // skipped: 236 MFMAs for the walking shape.  Row n of the product is x_c.
+  constexpr int cbd = n / 16;                            // the column block that holds the dense column [-b; b_eq]
+  auto kmin = [](int cb) { return (cb == cbd) ? 0 : cb; };   // first row block in which Y[.][cb] is not all zero
+  double rd[NRB][4];                                     // 1/d (pseudo-inverse rule folded in), per row of the tiles
 #pragma unroll
-  for (int I = 0; I < NRB; ++I) {
+  for (int K = 0; K < NRB; ++K) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = 16 * I + grp + 4 * r;
-      const double rd = (row < N) ? M[SH::cbase(row < N ? row : 0) + (row < N ? row : 0)] : 0.0;
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) X[I][cb][r] *= rd;
+      const int row = 16 * K + grp + 4 * r;
+      rd[K][r] = (row < N) ? M[SH::cbase(row < N ? row : 0) + (row < N ? row : 0)] : 0.0;
     }
   }
-  // ---- backward: X_I -= L_KI^T X_K (K > I), then X_I = L_II^-T X_I ---------------------------------------
+  lds_fence();                                           // every read of L is done: G goes over it
 #pragma unroll
-  for (int I = NRB - 1; I >= 0; --I) {
-    double aop[4 * NRB];
+  for (int I = 0; I < NCB; ++I) {
+    if (16 * I <= n) {                                   // (tiles whose rows are all beyond row n are never used)
+      d4 Gt[NCB];
 #pragma unroll
-    for (int t = 4 * I; t < NT; ++t) {
-      if (4 * t < N) {
-        double v = bwd[I][4 * t];                                     // L[4t + grp][16I + col]
-        bool keep = true;
-        if (I == NRB - 1 && kRowEdge < 16) keep = keep && (col < kRowEdge);   // column 16I + col < N
-        if (4 * t + 3 >= N) keep = keep && (4 * t + grp < N);
-        if (t < 4 * I + 4) keep = keep && (4 * (t - 4 * I) + grp > col);      // inverted diagonal block, transposed
-        aop[t] = keep ? ((t < 4 * I + 4) ? v : -v) : 0.0;
-      } else {
-        aop[t] = 0.0;
+      for (int J = 0; J < NCB; ++J) Gt[J] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int K = 0; K < NRB; ++K) {
+        if (K >= kmin(I)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (4 * (4 * K + r) < N) {
+              const double aop = X[K][I][r] * rd[K][r];
+#pragma unroll
+              for (int J = 0; J <= I; ++J)
+                if (K >= kmin(J)) Gt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[K][J][r], Gt[J], 0, 0, 0);
+            }
+          }
+        }
       }
-    }
 #pragma unroll
-    for (int t = 4 * I + 4; t < NT; ++t) {
-      if (4 * t < N) {
+      for (int J = 0; J <= I; ++J) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-          X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[t], X[t / 4][cb][t % 4], X[I][cb], 0, 0, 0);
-      }
-    }
-    d4 T[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) T[cb] = X[I][cb];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (4 * (4 * I + r) < N) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-          T[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[4 * I + r], X[I][cb][r], T[cb], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) X[I][cb] = T[cb];
-  }
-  // ---- rho * G and x_c to the lane = row layout, through LDS (L is dead) ---------------------------------
-  lds_fence();
-#pragma unroll
-  for (int I = 0; I < NRB; ++I) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * I + grp + 4 * r;
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const int c = 16 * cb + col;
-        if (row < n && c < n) M[row * n + c] = rho * X[I][cb][r];
-        if (row < n && c == n) vbuf[row] = X[I][cb][r];
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + grp + 4 * r, c = 16 * J + col;     // Gt[J][r] = (K_rho^-1)[row][c]
+          if (row < n && c < n) {
+            M[row * n + c] = rho * Gt[J][r];
+            if (J != I) M[c * n + row] = rho * Gt[J][r];               // the mirror tile
+          }
+          if (row == n && c < n) vbuf[c] = Gt[J][r];                   // x_c
+        }
       }
     }
   }

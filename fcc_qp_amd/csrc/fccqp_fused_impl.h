@@ -104,6 +104,14 @@ __device__ __forceinline__ double dpp_get(double v, double old) {
   int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// every lane reads lane K of its quad (all lanes active: no `old` value, no copy)
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v) {
+  constexpr int ctrl = K * 0x55;   // quad_perm [K,K,K,K]
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_get<0xB1, 0xf>(v, 0.0);   // quad_perm [1,0,3,2]
   v += dpp_get<0x4E, 0xf>(v, 0.0);   // quad_perm [2,3,0,1]
@@ -157,9 +165,10 @@ __device__ __forceinline__ double cone_lane_constant(double mu, bool is_z) {
 __device__ __forceinline__ double project_cone_component(double fx, double fy, double fz, double mu, double kc,
                                                          double v, bool is_z) {
   const double nxy2 = fx * fx + fy * fy;
-  const bool flat = !(nxy2 > 0.0);                      // f_xy == 0: inside if mu f_z >= 0, else origin
-  const double rs = fast_rsqrt(flat ? 1.0 : nxy2);
-  const double nxy = flat ? 0.0 : nxy2 * rs;
+  // f_xy == 0 (inside if mu f_z >= 0, else the origin): the clamp keeps the rsqrt finite, and then
+  // nxy = 0 * rs = 0 and dir = rs * 0 = 0 exactly, with no select
+  const double rs = fast_rsqrt(__builtin_fmax(nxy2, DBL_MIN));
+  const double nxy = nxy2 * rs;
   const bool inside = mu * fz >= nxy;                   // :10-12
   const bool polar = fz < -mu * nxy;                    // :15-17
   const double t = fma(mu, nxy, fz) * kc;               // :20-23, see above
@@ -206,6 +215,19 @@ struct Shape : Packed<N_VARS + N_EQ> {
   static constexpr int kLdsDoubles = kMat + kNp + kVbuf;
   static_assert(kLdsDoubles * 8 <= 160 * 1024 / 4, "four one-wave workgroups per CU");
   static_assert(n * n <= kMat, "rho G (n x n, row-major) fits over the dead factor");
+  // Lane <-> variable map of the ADMM loop.  Contact c owns lanes 4c, 4c+1, 4c+2 (x, y, z): a lane
+  // gets the three components of its contact force with quad_perm DPP moves instead of an LDS round
+  // trip per iteration.  The other variables fill the fourth lane of those quads, then the lanes past
+  // the contacts, in increasing order.  -1: the lane has no variable.
+  static constexpr int kContacts = nc / 3;
+  static_assert(4 * kContacts <= kWave, "one quad of lanes per contact");
+  __device__ static __forceinline__ int lane_variable(const int lane) {
+    const int q = lane >> 2, r = lane & 3;
+    const bool in_quad = q < kContacts;
+    const int k = in_quad ? q : lane - 3 * kContacts;      // index among the non-contact variables
+    const int other = (k < s) ? k : k + nc;
+    return (in_quad && r < 3) ? s + 3 * q + r : ((k < n - nc) ? other : -1);
+  }
 };
 
 
@@ -339,7 +361,7 @@ __device__ __forceinline__ void invert_diag_blocks(lds_f64 *M, const int lane) {
 
 template <class SH>
 __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho,
-                                        double (&Mrow)[SH::n], double &xc) {
+                                        const int grow, double (&Mrow)[SH::n], double &xc) {
   constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NCB = kWave / 16;
   static_assert(n < kWave, "n + 1 right-hand sides in 64 columns");
   const int col = lane & 15, grp = lane >> 4;
@@ -474,8 +496,10 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
     }
   }
   lds_fence();
-  const bool isvar = lane < n;
-  const int lr = isvar ? lane : 0;
+  // this lane takes row `grow` of rho G and entry `grow` of x_c (the ADMM loop's lane <-> variable map,
+  // Shape::lane_variable; -1: none)
+  const bool isvar = grow >= 0;
+  const int lr = isvar ? grow : 0;
   xc = isvar ? vbuf[lr] : 0.0;
   if constexpr (n % 2 == 0) {
     const lds_d2 *g2 = reinterpret_cast<const lds_d2 *>(M + lr * n);
@@ -709,19 +733,63 @@ __device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, doub
   }
 }
 
-// acc[j % kMvAcc] += Wq[j / 16](lane j % 16 of this lane's 16-lane row) * Mrow[j], j = J .. NN-1: the mat-vec of
-// an ADMM iteration with the vector operand fetched by the FMA itself (DPP row_newbcast); several
-// accumulators break the FMA dependency chain -- kMvAcc = 6 of them: a DPP instruction that reads a VGPR
-// a VALU instruction wrote fewer than five instructions earlier gets an s_nop from the hazard
-// recogniser (with four accumulators: one s_nop per four FMAs).  (A recursive template, not a lambda:
-// clang does not capture variables that a generic lambda only names in asm operands.)
-constexpr int kMvAcc = 6;
-template <int J, int NN, int NQ>
+// acc[i % kMvAcc] += w[16 q + i] * Mrow[16 q + i], i = 0 .. L-1: one 16-column block of the mat-vec of an
+// ADMM iteration, the vector operand fetched by the FMA itself (DPP row_newbcast from lane i of this
+// lane's 16-lane row of Wq, where Wq[lane] = w[16 q + (lane & 15)]).  ONE asm statement per block: the
+// hazard recogniser counts an inline-asm statement as zero wait states, so with one statement per FMA
+// it put an s_nop in front of every reuse of an accumulator whatever the distance (a dependent fp64 FMA
+// needs none).  Unused operands of the shorter last block are legal.
+constexpr int kMvAcc = 4;
+#define FCCQP_DPPF(A, M, L) "v_fmac_f64_dpp %" #A ", %4, %" #M " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
+#define FCCQP_S1 FCCQP_DPPF(0, 5, 0)
+#define FCCQP_S2 FCCQP_S1 FCCQP_DPPF(1, 6, 1)
+#define FCCQP_S3 FCCQP_S2 FCCQP_DPPF(2, 7, 2)
+#define FCCQP_S4 FCCQP_S3 FCCQP_DPPF(3, 8, 3)
+#define FCCQP_S5 FCCQP_S4 FCCQP_DPPF(0, 9, 4)
+#define FCCQP_S6 FCCQP_S5 FCCQP_DPPF(1, 10, 5)
+#define FCCQP_S7 FCCQP_S6 FCCQP_DPPF(2, 11, 6)
+#define FCCQP_S8 FCCQP_S7 FCCQP_DPPF(3, 12, 7)
+#define FCCQP_S9 FCCQP_S8 FCCQP_DPPF(0, 13, 8)
+#define FCCQP_S10 FCCQP_S9 FCCQP_DPPF(1, 14, 9)
+#define FCCQP_S11 FCCQP_S10 FCCQP_DPPF(2, 15, 10)
+#define FCCQP_S12 FCCQP_S11 FCCQP_DPPF(3, 16, 11)
+#define FCCQP_S13 FCCQP_S12 FCCQP_DPPF(0, 17, 12)
+#define FCCQP_S14 FCCQP_S13 FCCQP_DPPF(1, 18, 13)
+#define FCCQP_S15 FCCQP_S14 FCCQP_DPPF(2, 19, 14)
+#define FCCQP_S16 FCCQP_S15 FCCQP_DPPF(3, 20, 15)
+#define FCCQP_DPP_BLOCK(STR)                                                                          \
+  asm(STR : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                    \
+      : "v"(w), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), \
+        "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]))
+template <int L>
+__device__ __forceinline__ void dpp_block(double (&acc)[kMvAcc], const double w, const double (&m)[16]) {
+  static_assert(L >= 1 && L <= 16, "one 16-lane row");
+  if constexpr (L == 16) FCCQP_DPP_BLOCK(FCCQP_S16);
+  else if constexpr (L == 15) FCCQP_DPP_BLOCK(FCCQP_S15);
+  else if constexpr (L == 14) FCCQP_DPP_BLOCK(FCCQP_S14);
+  else if constexpr (L == 13) FCCQP_DPP_BLOCK(FCCQP_S13);
+  else if constexpr (L == 12) FCCQP_DPP_BLOCK(FCCQP_S12);
+  else if constexpr (L == 11) FCCQP_DPP_BLOCK(FCCQP_S11);
+  else if constexpr (L == 10) FCCQP_DPP_BLOCK(FCCQP_S10);
+  else if constexpr (L == 9) FCCQP_DPP_BLOCK(FCCQP_S9);
+  else if constexpr (L == 8) FCCQP_DPP_BLOCK(FCCQP_S8);
+  else if constexpr (L == 7) FCCQP_DPP_BLOCK(FCCQP_S7);
+  else if constexpr (L == 6) FCCQP_DPP_BLOCK(FCCQP_S6);
+  else if constexpr (L == 5) FCCQP_DPP_BLOCK(FCCQP_S5);
+  else if constexpr (L == 4) FCCQP_DPP_BLOCK(FCCQP_S4);
+  else if constexpr (L == 3) FCCQP_DPP_BLOCK(FCCQP_S3);
+  else if constexpr (L == 2) FCCQP_DPP_BLOCK(FCCQP_S2);
+  else FCCQP_DPP_BLOCK(FCCQP_S1);
+}
+template <int Q, int NN, int NQ>
 __device__ __forceinline__ void dpp_matvec(double (&acc)[kMvAcc], const double (&Wq)[NQ], const double (&Mrow)[NN]) {
-  if constexpr (J < NN) {
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc[J % kMvAcc]) : "v"(Wq[J / 16]), "v"(Mrow[J]), "n"(J % 16));
-    dpp_matvec<J + 1, NN, NQ>(acc, Wq, Mrow);
+  if constexpr (Q < NQ) {
+    constexpr int L = (NN - 16 * Q < 16) ? NN - 16 * Q : 16;
+    double m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = Mrow[(16 * Q + i < NN) ? 16 * Q + i : NN - 1];
+    dpp_block<L>(acc, Wq[Q], m);
+    dpp_matvec<Q + 1, NN, NQ>(acc, Wq, Mrow);
   }
 }
 
@@ -752,18 +820,23 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   double *mux_s = a.mu_x + (size_t)inst * n;
   double *mulc_s = a.mu_lc + (size_t)inst * nc;
 
-  // ---- vectors, variable layout: lane i <-> variable i (i < n); lane r <-> equality row r ----
+  // ---- vectors.  Two lane <-> variable maps: the natural one (lane i <-> variable i, i < n; lane r <->
+  // equality row r) for the assembly, the right-hand side and the presolve solve, and
+  // Shape::lane_variable (each contact in a quad of lanes) for rho G, the ADMM loop and the epilogue ----
   // The small vectors (b, b_eq, lb, ub, mu, warm-start state) are fetched from global memory at
   // the point of use instead of being held in registers across the phases: P3 needs nearly the
   // whole register file, and anything live across it is spilled to scratch and reloaded inside
   // the ADMM loop.  `fresh()` hides the pointer from CSE so the loads really are redone.
   auto fresh = [](const double *p) { asm volatile("" : "+s"(p)); return p; };
-  const bool isvar = lane < n;
-  const bool is_cone = (lane >= s0) && (lane < s0 + nc);
-  const int cidx = is_cone ? (lane - s0) / 3 : 0;
-  const int ccomp = is_cone ? (lane - s0) - 3 * cidx : 0;
+  const bool isnat = lane < n;
+  const int var = SH::lane_variable(lane);
+  const bool isvar = var >= 0;
+  const int vi = isvar ? var : 0;
+  const bool is_cone = ((lane >> 2) < SH::kContacts) && ((lane & 3) < 3);
+  const int cidx = is_cone ? (lane >> 2) : 0;
+  const int ccomp = is_cone ? (lane & 3) : 0;
   double x = 0.0;
-  if (a.warm_start) x = isvar ? xs[lane] : 0.0;  // fcc_qp.cpp:136-139 (duals are fetched at P4)
+  if (a.warm_start) x = isvar ? xs[vi] : 0.0;  // fcc_qp.cpp:136-139 (duals are fetched at P4)
   // nc > 0: never the reference's equality-only case (fcc_qp.cpp:132-133)
   int flags = 0;
   long long ticks = 0;
@@ -838,7 +911,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     const double *bp = fresh(bq), *ep = fresh(beq);
     // both loads before the first LDS store: with the fence between them they were two dependent
     // HBM round trips
-    const double vb = isvar ? -bp[lane] : 0.0;
+    const double vb = isnat ? -bp[lane] : 0.0;
     const double ve = (lane < m) ? ep[lane < m ? lane : 0] : 0.0;
     vbuf[lane] = vb;
     lds_fence();
@@ -869,7 +942,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     double xc;
     stage_rhs();
     const long long t3 = wall_clock64();
-    p3_mfma<SH>(M, vbuf, lane, a.rho, Mrow, xc);
+    p3_mfma<SH>(M, vbuf, lane, a.rho, var, Mrow, xc);
     long long t4 = wall_clock64();
     ph_p3 = t4 - t3;
 
@@ -892,14 +965,14 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     if (!a.warm_start) {
       using SW = typename SH::Reduced;
       flags |= kFlagPresolveRan;
-      // W, packed lower, over the rho G image in LDS (row `lane` of rho G is in registers by now)
+      // W, packed lower, over the rho G image in LDS (row `var` of rho G is in registers by now)
 #pragma unroll
       for (int j = 0; j < n; ++j)
-        if (lane >= j && isvar) M[SW::cbase(j) + lane] = ((lane == j) ? 1.0 : 0.0) - Mrow[j];
+        if (var >= j) M[SW::cbase(j) + var] = ((var == j) ? 1.0 : 0.0) - Mrow[j];
       lds_fence();
       const long long tw = wall_clock64();
       bool wbad = factor_lds<SW>(M, dvec, lane);
-      const double dw = dvec[isvar ? lane : 0];
+      const double dw = dvec[vi];
       wbad = wbad || __any(!(dw > kPresolveMinPivot));
       ticks += wall_clock64() - tw;
       if (wbad) {
@@ -914,9 +987,14 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
           return;
         }
       }
-      double r0 = xc, r1 = 0.0;
+      // the solve runs in the natural layout (x_c is still in vbuf[0..n) from P3); its result goes
+      // through vbuf to the lanes of the ADMM loop
+      double r0 = isnat ? vbuf[isnat ? lane : 0] : 0.0, r1 = 0.0;
       solve_lds<SW>(M, lane, r0, r1);
-      x = isvar ? r0 : 0.0;
+      lds_fence();
+      vbuf[lane] = r0;
+      lds_fence();
+      x = isvar ? vbuf[vi] : 0.0;
       lds_fence();
       const long long t5 = wall_clock64();
       ph_solve = t5 - t4;
@@ -924,17 +1002,16 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     }
 
     // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------
-    const double vlb = isvar ? fresh(lbp)[lane] : -HUGE_VAL;
-    const double vub = isvar ? fresh(ubp)[lane] : HUGE_VAL;
+    const double vlb = isvar ? fresh(lbp)[vi] : -HUGE_VAL;
+    const double vub = isvar ? fresh(ubp)[vi] : HUGE_VAL;
     const double vmu = is_cone ? fresh(mup)[cidx] : 0.0;
     double mux = 0.0, mulc = 0.0;
     if (a.warm_start) {  // fcc_qp.cpp:136-139
-      mux = isvar ? mux_s[lane] : 0.0;
-      mulc = is_cone ? mulc_s[lane - s0] : 0.0;
+      mux = isvar ? mux_s[vi] : 0.0;
+      mulc = is_cone ? mulc_s[is_cone ? vi - s0 : 0] : 0.0;
     }
     double xbar = x, lcbar = x;  // :74-75
     double xr = 0.0, lr = 0.0;
-    n_iter = a.max_iter;         // :78
     // The loop's wave-uniform operands (lane masks, the two eps) are re-made here as per-lane
     // VGPR values: as SGPRs their live ranges span P3, the allocator spills them to VGPR lanes and
     // the loop reloads each one with v_readlane pairs + wait states, several times per iteration;
@@ -943,26 +1020,33 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     double eps_b = a.eps_bound, eps_f = a.eps_fcone;
     const double vkc = cone_lane_constant(vmu, ccomp == 2);
     asm volatile("" : "+v"(var_i), "+v"(cone_i), "+v"(z_i), "+v"(eps_b), "+v"(eps_f));
+    // w goes to vbuf[variable]; lanes without a variable write entry 63, which is no variable's (n < 64)
+    // and is never multiplied (the mat-vec stops at column n-1)
+    lds_f64 *const wslot = vbuf + (isvar ? var : kWave - 1);
+    // the trip count as a fresh SGPR: the kernarg copy's live range spans P3 and it is spilled to a VGPR
+    // lane, read back by v_readlane on every iteration
+    int max_iter = a.max_iter;
+    asm volatile("" : "+s"(max_iter));
+    n_iter = max_iter;           // :78
 #pragma nounroll
-    for (int iter = 0; iter < a.max_iter; ++iter) {
+    for (int iter = 0; iter < max_iter; ++iter) {
       // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
       const double w = (cone_i != 0) ? (lcbar - mulc) : (xbar - mux);
-      vbuf[lane] = (var_i != 0) ? w : 0.0;
+      *wslot = w;
       lds_fence();
-      // x = x_c + (rho G) w   == the KKT solve of :83-87, lane i = row i of rho G.  Every lane needs all
+      // x = x_c + (rho G) w   == the KKT solve of :83-87, this lane = row `var` of rho G.  Every lane needs all
       // of w.  Reading it back as LDS broadcasts (ds_read_b128 of two doubles into all 64 lanes: a
       // 1-KiB return per instruction) made the four waves of a CU wait on the LDS return path: 409 ns
       // per mat-vec.  Instead each 16-lane row takes a copy of w, 16 entries per register
       // (Wq[lane] = w[16 q + (lane & 15)]: NQ plain ds_read_b64), and the FMA itself fetches its
       // operand from lane l of the row (v_fmac_f64 with the DPP control row_newbcast:l, the one DPP
-      // mode the fp64 ALU has): no LDS traffic, no extra instruction -- 216 ns against the 136 ns floor
-      // of 60 FMAs with register operands (tools/dpp_bench.hip).
+      // mode the fp64 ALU has): no LDS traffic, no extra instruction (tools/dpp_bench.hip).
       constexpr int NQ = (n + 15) / 16;
       double Wq[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];   // entries >= n were written as 0
+      for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];
       lds_fence();
-      double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0};
       // the DPP read of a VGPR needs two wait states after a VALU write of it (the registers come
       // straight from the LDS reads, but a copy could be scheduled in between): pin them here
       if constexpr (NQ == 4) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]), "+v"(Wq[3]));
@@ -970,27 +1054,27 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       else if constexpr (NQ == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
       else asm volatile("s_nop 1" : "+v"(Wq[0]));
       dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
-      const double acc0 = acc[0] + acc[4], acc1 = acc[1] + acc[5], acc2 = acc[2], acc3 = acc[3];
-      x = (acc0 + acc1) + (acc2 + acc3);
-      lds_fence();
-      // slack update :90-92
-      if (cone_i != 0) vbuf[lane] = x + mulc;
-      lds_fence();
-      xr = 0.0; lr = 0.0;
-      if (var_i != 0) {
+      x = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in lanes 4c .. 4c+2 of
+      // this lane's quad: three quad_perm broadcasts (v_mov_b32 DPP pairs), no LDS round trip
+      const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused
+      const double cfx = quad_bcast<0>(xm), cfy = quad_bcast<1>(xm), cfz = quad_bcast<2>(xm);
+      // Every lane runs both updates, unmasked (a select per state variable per iteration otherwise).  A
+      // lane without a variable has x = mu_x = 0 and infinite bounds: it stays at zero.  Outside the
+      // contacts lcbar / lr / mulc are garbage that nothing reads: w, the exit test, the reported norms
+      // and the write-back all select on the lane's kind.
+      {
         const double v = x + mux;
         const double tt = min2(v, vub);   // std::min(x(i), ub(i))   constraint_utils.cpp:43
         xbar = max2(tt, vlb);             // std::max(., lb(i))
         xr = x - xbar;                    // :95
         mux += xr;                        // :101
       }
-      if (cone_i != 0) {
-        const int base = s0 + 3 * cidx;
-        lcbar = project_cone_component(vbuf[base], vbuf[base + 1], vbuf[base + 2], vmu, vkc, x + mulc, z_i != 0);
+      {
+        lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_i != 0);
         lr = x - lcbar;                   // :96
         mulc += lr;                       // :102
       }
-      lds_fence();
       // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test
       // is one ballot instead of two wave reductions; the norms themselves (:97-98) are only
       // reported, and are reduced once after the loop.  An empty contact set has norm 0.
@@ -1007,31 +1091,30 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       lc_res_norm = wave_max(is_cone ? fabs(lr) : 0.0);
     }
     // duals are part of the warm-start state (fcc_qp.hpp:149-150)
-    if (isvar) mux_s[lane] = mux;
-    if (is_cone) mulc_s[lane - s0] = mulc;
+    if (isvar) mux_s[vi] = mux;
+    if (is_cone) mulc_s[vi - s0] = mulc;
     ph_p4 = wall_clock64() - t4;
   }
 
   // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back -----------------------------------------
   lds_fence();
-  if (is_cone) vbuf[lane] = x;
-  lds_fence();
+  const double ffy = quad_bcast<1>(x), ffz = quad_bcast<2>(x);   // this quad's contact force
   double bv = 0.0, cv = 0.0;
   if (isvar) {
-    const double tt = min2(x, fresh(ubp)[lane]);
-    const double p = max2(tt, fresh(lbp)[lane]);
+    const double tt = min2(x, fresh(ubp)[vi]);
+    const double p = max2(tt, fresh(lbp)[vi]);
     const double dd = x - p;
     bv = dd * dd;                                        // constraint_utils.cpp:61-65
   }
   if (is_cone && ccomp == 0) {
-    const double fx = vbuf[lane], fy = vbuf[lane + 1], fz = vbuf[lane + 2];
+    const double fx = x, fy = ffy, fz = ffz;
     const double v = sqrt(fx * fx + fy * fy) - fresh(mup)[cidx] * fz;
     cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
   }
   bv = sqrt(wave_sum(bv));
   cv = wave_sum(cv);
 
-  if (isvar) xs[lane] = x;
+  if (isvar) xs[vi] = x;
   if (lane == 0) {
     a.n_iter[inst] = n_iter;
     a.flags[inst] = flags;

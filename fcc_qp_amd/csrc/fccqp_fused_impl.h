@@ -87,6 +87,14 @@ __device__ __forceinline__ void lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Development aid: -DFCCQP_FINE_STAMPS splits the factorisation time (100 MHz ticks, summed over the
+// panels of both factorisations) into bulk update / panel load + store / in-panel steps and reports
+// them in phase slots 6, 7 and 0 (tools/quick_bench.py prints the slots).
+#ifdef FCCQP_FINE_STAMPS
+#define FCCQP_FINE(slot, expr) do { const long long t_ = wall_clock64(); expr; if (fine) fine[slot] += wall_clock64() - t_; } while (0)
+#else
+#define FCCQP_FINE(slot, expr) do { expr; } while (0)
+#endif
 __device__ __forceinline__ double bcast_lane(double v, int src_lane) {  // src_lane wave-uniform
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -193,7 +201,12 @@ struct Packed {
   static constexpr int cbase(int j) { return cstart(j) - j; }
   // cbase(j + 1) - cbase(j): lets loops walk the columns with one scalar add
   static constexpr int cstep(int j) { return N - j - 1 + (((j & 1) == (N & 1)) ? 1 : 0); }
-  static constexpr int kMat = (cstart(N) + 1) & ~1;
+  static constexpr int kPacked = (cstart(N) + 1) & ~1;
+  // The image doubles as the exchange scratch of tile_factor_forward (kScratch doubles at its start) and
+  // keeps the reciprocal pivots of all (padded) rows behind both the scratch and the later rho G image.
+  static constexpr int kScratch = 544;
+  static constexpr int kRowsPadded = 16 * ((N + 15) / 16);
+  static constexpr int kMat = (kPacked > kScratch + kRowsPadded) ? kPacked : kScratch + kRowsPadded;
   static constexpr int kNp = (N + 1) & ~1;
 };
 
@@ -214,7 +227,9 @@ struct Shape : Packed<N_VARS + N_EQ> {
   static constexpr int kVbuf = (kNp > kWave) ? kNp : kWave;
   static constexpr int kLdsDoubles = kMat + kNp + kVbuf;
   static_assert(kLdsDoubles * 8 <= 160 * 1024 / 4, "four one-wave workgroups per CU");
-  static_assert(n * n <= kMat, "rho G (n x n, row-major) fits over the dead factor");
+  static_assert(n * n + KKT::kRowsPadded <= kMat, "rho G (n x n, row-major) and 1/d fit over the dead factor");
+  // where tile_factor_forward leaves 1/d_row for gram_output
+  static constexpr int kRcpOffset = (n * n > KKT::kScratch) ? n * n : KKT::kScratch;
   // Lane <-> variable map of the ADMM loop.  Contact c owns lanes 4c, 4c+1, 4c+2 (x, y, z): a lane
   // gets the three components of its contact force with quad_perm DPP moves instead of an LDS round
   // trip per iteration.  The other variables fill the fourth lane of those quads, then the lanes past
@@ -309,138 +324,17 @@ __device__ __forceinline__ void mfma_bulk_rb(lds_f64 *M, const lds_f64 *dvec, co
 }
 
 
-// ---- P3 on the matrix cores ------------------------------------------------------------------------
-// X := (L D L^T)^-1 X for the N x 64 block X = [e_0 .. e_{n-1} | -b; b_eq | 0 ..]: a triangular
-// solve with 64 right-hand sides, i.e. a real contraction.  X lives in MFMA accumulator tiles
-// (row block I of 16 rows x column block cb of 16 right-hand sides: 4 doubles per lane, C/D layout
-// col = lane & 15, row = (lane >> 4) + 4 r).  Forward sweep by row blocks:
-//   X_I -= L_IK X_K  (K < I)     v_mfma_f64_16x16x4: A[i][k] = L[16I+i][16K+4r+k] is one ds_read_b64
-//                                per lane (no broadcast), and B[k][n] = X_K[4r+k][n] IS accumulator
-//                                register r of tile X_K -- no data movement at all;
-//   X_I  = L_II^-1 X_I           with the 16x16 diagonal blocks inverted in place beforehand.
-// Then D^-1 (the diagonal slots hold 1/d), the mirrored backward sweep with L^T, and rho*G / x_c go
-// through LDS (over L, which is dead by then) to the lane = row layout the ADMM loop wants.
-// Against the lane-per-right-hand-side VALU version this replaces ~9.6 k FMA + 4.8 k broadcast
-// ds_read_b128 instructions by ~0.8 k MFMA + ~0.3 k ds_read_b64, and 19 k lines of generated code.
+// rho G = rho Y^T D^-1 Y (n x n) and x_c (row n of the product) from the forward result Y (tiles X) and the
+// reciprocal pivots rd; rho G goes through LDS (over the dead matrix image) to Mrow = row `grow` of rho G.
 template <class SH>
-__device__ __forceinline__ void invert_diag_blocks(lds_f64 *M, const int lane) {
-  constexpr int N = SH::N, NRB = (N + 15) / 16;
-  // pair p = 16 * block + column: lane handles pairs lane, 64 + lane; y = column j of L_II^-1
-#pragma unroll
-  for (int round = 0; round * kWave < 16 * NRB; ++round) {
-    const int p = round * kWave + lane;
-    const int blk = p >> 4, j = p & 15, r0 = 16 * blk;
-    const bool live = p < 16 * NRB;
-    double y[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) y[i] = (i == j) ? 1.0 : 0.0;
-    // column k of this lane's block starts at colp[k] (row r0): rows are immediate offsets.  Dead
-    // lanes and rows / columns past N-1 read in-bounds garbage that is masked to zero.
-    const lds_f64 *colp[15];
-#pragma unroll
-    for (int k = 0; k < 15; ++k) {
-      const int c = (live && r0 + k < N) ? r0 + k : 0;
-      colp[k] = M + SH::cbase(c) + (live ? r0 : 0);
-    }
-    const int nrow = live ? N - r0 : 0;                             // valid rows in this block
-#pragma unroll
-    for (int i = 1; i < 16; ++i) {
-      double l[15];
-#pragma unroll
-      for (int k = 0; k < i; ++k) l[k] = colp[k][i];
-#pragma unroll
-      for (int k = 0; k < i; ++k) y[i] = fma(-((i < nrow) ? l[k] : 0.0), y[k], y[i]);
-    }
-    lds_fence();   // every lane has read its block before any lane overwrites one
-#pragma unroll
-    for (int i = 1; i < 16; ++i)
-      if (live && i > j && r0 + i < N) M[SH::cbase(r0 + j) + r0 + i] = y[i];
-    lds_fence();
-  }
-}
-
-template <class SH>
-__device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho,
-                                        const int grow, double (&Mrow)[SH::n], double &xc) {
+__device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho, const int grow,
+                                            const d4 (&X)[(SH::N + 15) / 16][kWave / 16], double (&Mrow)[SH::n], double &xc,
+                                            long long *fine = nullptr) {
   constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NCB = kWave / 16;
-  static_assert(n < kWave, "n + 1 right-hand sides in 64 columns");
   const int col = lane & 15, grp = lane >> 4;
-  invert_diag_blocks<SH>(M, lane);
-  // right-hand sides: column c < n is e_c, column n is [-b; b_eq] (staged in vbuf), the rest zero
-  d4 X[NRB][NCB];
-#pragma unroll
-  for (int I = 0; I < NRB; ++I) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * I + grp + 4 * r;
-      const double rhs = (row < N) ? vbuf[row < N ? row : 0] : 0.0;
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const int c = 16 * cb + col;
-        X[I][cb][r] = (c < n) ? ((row == c) ? 1.0 : 0.0) : ((c == n) ? rhs : 0.0);
-      }
-    }
-  }
-  lds_fence();
-  // A operands.  Forward: A[i][k] = L[16I + i][4t + k], t = 4K + r: per-lane column base
-  // fwd[t] = &M[cbase(4t + grp) + col], row block = immediate offset 16I.  Backward: A[i][k] =
-  // L[4t + k][16I + i]: bwd[I] = &M[cbase(16I + col) + grp], offset 4t.  Entries outside the
-  // matrix (rows / columns >= N: last row block, k-step t = N/4) and outside the strict triangle
-  // of a diagonal block are zeroed by a select after an in-bounds load; which tiles need that is
-  // known at compile time.  All operands of a row block are fetched before its MFMAs.
-  constexpr int NT = 4 * NRB;
-  const lds_f64 *fwd[NT], *bwd[NRB];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) fwd[t] = M + SH::cbase((4 * t + grp < N) ? 4 * t + grp : N - 1) + col;
-#pragma unroll
-  for (int I = 0; I < NRB; ++I) bwd[I] = M + SH::cbase((16 * I + col < N) ? 16 * I + col : N - 1) + grp;
-  constexpr int kRowEdge = N - 16 * (NRB - 1);   // valid rows in the last row block
-  // ---- forward ------------------------------------------------------------------------------------
-#pragma unroll
-  for (int I = 0; I < NRB; ++I) {
-    double aop[4 * NRB];
-#pragma unroll
-    for (int t = 0; t < 4 * I + 4; ++t) {
-      if (4 * t < N) {
-        double v = fwd[t][16 * I];                                   // rows past N-1 land in allocated LDS
-        bool keep = true;
-        if (I == NRB - 1 && kRowEdge < 16) keep = keep && (col < kRowEdge);
-        if (4 * t + 3 >= N) keep = keep && (4 * t + grp < N);
-        if (t >= 4 * I) keep = keep && (col > 4 * (t - 4 * I) + grp);   // inverted diagonal block: strict lower
-        aop[t] = keep ? ((t >= 4 * I) ? v : -v) : 0.0;
-      } else {
-        aop[t] = 0.0;
-      }
-    }
-    // In the forward sweep tile X_K of column block cb is still all zero while every unit entry of
-    // the block lies below row block K (columns 16 cb .. are e_c with c >= 16 cb); the block that
-    // holds the dense column [-b; b_eq] (c == n) is the exception.  Those products are skipped.
-    auto zero_tile = [](int K, int cb) { return K < cb && cb != n / 16; };
-#pragma unroll
-    for (int t = 0; t < 4 * I; ++t) {
-      if (4 * t < N) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-          if (!zero_tile(t / 4, cb))
-            X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[t], X[t / 4][cb][t % 4], X[I][cb], 0, 0, 0);
-      }
-    }
-    // X_I = L_II^-1 X_I = X_I + (strictly lower part of the inverted block) X_I
-    d4 T[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) T[cb] = X[I][cb];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (4 * (4 * I + r) < N) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-          if (!zero_tile(I, cb))
-            T[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[4 * I + r], X[I][cb][r], T[cb], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) X[I][cb] = T[cb];
-  }
+#ifdef FCCQP_FINE_STAMPS
+  const long long tg_ = wall_clock64();
+#endif
   // ---- G = Y^T D^-1 Y with Y = L^-1 [E | r] (the forward result) -------------------------------------
   // (K_rho^-1)[0:n, 0:n] = E^T L^-T D^-1 L^-1 E: instead of the backward sweep with L^T -- 364 MFMAs
   // chained through the row blocks, each with an operand out of LDS -- the product of the forward
@@ -451,16 +345,14 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
   // skipped: 236 MFMAs for the walking shape.  Row n of the product is x_c.
   constexpr int cbd = n / 16;                            // the column block that holds the dense column [-b; b_eq]
   auto kmin = [](int cb) { return (cb == cbd) ? 0 : cb; };   // first row block in which Y[.][cb] is not all zero
-  double rd[NRB][4];                                     // 1/d (pseudo-inverse rule folded in), per row of the tiles
+  // 1/d per tile row, left behind the rho G image by tile_factor_forward (kept there rather than in 56
+  // registers across the factorisation)
+  double rd[NRB][4];
 #pragma unroll
-  for (int K = 0; K < NRB; ++K) {
+  for (int K = 0; K < NRB; ++K)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * K + grp + 4 * r;
-      rd[K][r] = (row < N) ? M[SH::cbase(row < N ? row : 0) + (row < N ? row : 0)] : 0.0;
-    }
-  }
-  lds_fence();                                           // every read of L is done: G goes over it
+    for (int r = 0; r < 4; ++r) rd[K][r] = M[SH::kRcpOffset + 16 * K + grp + 4 * r];
+  lds_fence();
 #pragma unroll
   for (int I = 0; I < NCB; ++I) {
     if (16 * I <= n) {                                   // (tiles whose rows are all beyond row n are never used)
@@ -496,6 +388,10 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
     }
   }
   lds_fence();
+#ifdef FCCQP_FINE_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (fine) fine[2] += wall_clock64() - tg_;
+#endif
   // this lane takes row `grow` of rho G and entry `grow` of x_c (the ADMM loop's lane <-> variable map,
   // Shape::lane_variable; -1: none)
   const bool isvar = grow >= 0;
@@ -516,6 +412,262 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
   lds_fence();
 }
 
+// ---- K_rho = U^T D U by 16 x 16 tiles held in registers, with the forward solve fused in ---------------
+// Right-looking, upper-triangular form.  The tiles C[I][J] (J >= I) of the upper triangle and the
+// right-hand-side tiles X[I][cb] of [e_0 .. e_{n-1} | -b; b_eq] live in MFMA accumulator layout (col =
+// lane & 15, row = (lane >> 4) + 4 r) for the whole factorisation.  For row panel p:
+//   (1) the diagonal tile C_pp = L D L^T (L = U_pp^T) is factorised and L^-1 formed on the VALU
+//       (tile_ldl below: a trip through LDS to a column-per-lane layout and back);
+//   (2) V_pj = L^-1 C_pj (= D U_pj) for the tiles right of it and Y_p = L^-1 X_p:  MFMAs whose A operand is
+//       the inverse tile and whose B operand IS register r of the tile being solved;
+//   (3) C_ij -= V_pi^T D^-1 V_pj and X_i -= V_pi^T D^-1 Y_p for the rows below:  both contract over the ROWS
+//       of panel-p tiles, so A (= register r of V_pi: A[i][k] = V_pi[4r+k][i]) and B (= register r of
+//       U_pj / Y_p) come straight out of the accumulators -- no operand is ever read from LDS, no tile is
+//       ever written back to it, and the panel's tiles are dead once step (3) is done (the factor itself
+//       is not kept: G = Y^T D^-1 Y needs only Y and D).
+// Against the left-looking LDS version (factor_lds + the forward sweep of p3_mfma) this removes the panel
+// loads / stores (10 us per QP), the per-k-step operand fetches and the 98-row-high in-panel updates with
+// their v_readlane pairs (the serial part shrinks to the 16 x 16 diagonal tiles).  Same elimination
+// order (natural, unpivoted), same pivot rules as factor_panel.
+__device__ __forceinline__ double pivot_inverse(double dd) {   // Eigen's LDLT::solve drops |d| <= DBL_MIN
+  const double r = fast_rcp(dd);
+  return (fabs(dd) > DBL_MIN) ? r : 0.0;
+}
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {   // lane K of this lane's 16-lane row
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// t += t(lane K of the row) * f   /   y += l(lane K of the row) * f.   volatile: these keep their program
+// order, which is what spaces a DPP read of a VGPR from the VALU write of it (2 wait states; the
+// hazard recogniser does not look inside asm statements) -- see the s_nop notes in tile_ldl.
+template <int K>
+__device__ __forceinline__ void dpp_self_fma(double &t, const double f) {
+  asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(f), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void dpp_fma(double &y, const double l, const double f) {
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(l), "v"(f), "n"(K));
+}
+// Elimination step K of the diagonal tile: column c (this lane) takes  S_ic -= S_iK (S_Kc / d_K), i > K, for
+// c > K; the pivot of step K+1 is broadcast and inverted right after the first update (look-ahead).
+template <int K, int I>
+__device__ __forceinline__ void tile_step_rows(double (&T)[16], const double negm) {
+  if constexpr (I < 16) {
+    dpp_self_fma<K>(T[I], negm);
+    tile_step_rows<K, I + 1>(T, negm);
+  }
+}
+template <int K>
+__device__ __forceinline__ void tile_steps(double (&T)[16], double d, double rinv, double &dmine, double &rmine,
+                                           const int c) {
+  if constexpr (K < 16) {
+    dmine = (c == K) ? d : dmine;
+    rmine = (c == K) ? rinv : rmine;
+    if constexpr (K < 15) {
+      const double negm = (c > K) ? -(T[K] * rinv) : 0.0;
+      // steps 12 .. 14 have fewer than two other updates between the write of T[i] by step K-1 and its
+      // DPP read here
+      if constexpr (K >= 12) asm volatile("s_nop 1" : "+v"(T[K + 1]));
+      dpp_self_fma<K>(T[K + 1], negm);
+      asm volatile("s_nop 1" : "+v"(T[K + 1]));        // VALU write -> DPP read of the next pivot
+      const double dn = row_bcast<K + 1>(T[K + 1]);
+      const double rn = pivot_inverse(dn);
+      tile_step_rows<K, K + 2>(T, negm);
+      tile_steps<K + 1>(T, dn, rn, dmine, rmine, c);
+    }
+  }
+}
+template <int K, int I>
+__device__ __forceinline__ void tile_inverse_rows(double (&Y)[16], const double (&Ls)[16]) {
+  if constexpr (I < 16) {
+    dpp_fma<K>(Y[I], Ls[I], Y[K]);
+    tile_inverse_rows<K, I + 1>(Y, Ls);
+  }
+}
+template <int K>
+__device__ __forceinline__ void tile_inverse_steps(double (&Y)[16], const double (&Ls)[16]) {
+  if constexpr (K < 15) {
+    tile_inverse_rows<K, K + 1>(Y, Ls);
+    tile_inverse_steps<K + 1>(Y, Ls);
+  }
+}
+// Diagonal tile, column-per-lane (every 16-lane row of the wave holds a copy and does the same work):
+// in  T[i] = S[i][c], the symmetric 16 x 16 block;
+// out dmine = d_c, rmine = 1/d_c (pseudo-inverse rule), Y[i] = (L^-1)[i][c] for i > c (Y[c] = 1, Y[i < c] = 0).
+template <int NVALID>
+__device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], double &dmine, double &rmine, const int c) {
+  dmine = 1.0; rmine = 1.0;
+  const double d0 = row_bcast<0>(T[0]);
+  tile_steps<0>(T, d0, pivot_inverse(d0), dmine, rmine, c);
+  // zero, infinite or NaN pivot (class mask: sNaN|qNaN|-inf|-0|+0|+inf), judged once: lane c holds d_c.
+  // (Padding rows are identity.)
+  const bool bad = __any((c < NVALID) && __builtin_amdgcn_class(dmine, 0x3 | 0x4 | 0x20 | 0x40 | 0x200));
+  // lane c now holds S_ic^(c) = l_ic d_c for i > c.  L^-1 by columns: y_i -= l_iK y_K, K < i, with l_iK fetched
+  // from lane K (negated and scaled here, once)
+  // (in place: T becomes -L)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    T[i] = -(T[i] * rmine);
+    Y[i] = (i == c) ? 1.0 : 0.0;
+  }
+  asm volatile("s_nop 1" : "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]), "+v"(T[8]));
+  asm volatile("s_nop 1" : "+v"(T[9]), "+v"(T[10]), "+v"(T[11]), "+v"(T[12]), "+v"(T[13]), "+v"(T[14]), "+v"(T[15]));
+  tile_inverse_steps<0>(Y, T);
+  return bad;
+}
+
+template <class SH>
+__device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, const int lane,
+                                                    d4 (&X)[(SH::N + 15) / 16][kWave / 16], long long *fine = nullptr) {
+  constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NCB = kWave / 16;
+  static_assert(n < kWave, "n + 1 right-hand sides in 64 columns");
+
+  const int col = lane & 15, grp = lane >> 4;
+  auto zero_tile = [](int K, int cb) { return K < cb && cb != n / 16; };   // see p3_mfma
+  // ---- tiles of the upper triangle out of the packed image (element (i, j), i <= j, is packed (j, i)) -----
+  // Row panel 0 is loaded here; the other tiles are loaded when panel 0 first updates them (28 tiles +
+  // the diagonal-tile work of panel 0 do not fit the register file).  The exchange scratch of the
+  // diagonal tiles is the start of the packed image -- columns 0 .. 15, dead once row panel 0 is in
+  // registers -- so the rest of the image stays readable through panel 0.  (Tiny shapes, whose whole
+  // image is smaller than the scratch, load everything up front.)
+  d4 C[NRB][NRB];
+  auto load_tile = [&](const int I, const int J) {
+    d4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * I + grp + 4 * r, j = 16 * J + col;
+      const int ic = (i < N) ? i : N - 1, jc = (j < N) ? j : N - 1;
+      double v;
+      if (J == I) {
+        const int lo = (ic < jc) ? ic : jc, hi = (ic < jc) ? jc : ic;
+        v = M[SH::cbase(lo) + hi];
+        if (16 * I + 15 >= N) v = (i < N && j < N) ? v : ((i == j) ? 1.0 : 0.0);   // identity padding
+      } else {
+        v = M[SH::cbase(ic) + jc];
+        if (16 * J + 15 >= N) v = (j < N) ? v : 0.0;
+        if (16 * I + 15 >= N) v = (i < N) ? v : 0.0;
+      }
+      t[r] = v;
+    }
+    return t;
+  };
+  constexpr int kScratch = SH::kScratch;
+  constexpr bool kLazy = NRB > 1 && SH::cbase(16 < N ? 16 : 0) + 16 >= kScratch;
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+    if (I == 0 || !kLazy) {
+#pragma unroll
+      for (int J = I; J < NRB; ++J) C[I][J] = load_tile(I, J);
+    }
+  }
+  // right-hand sides: column c < n is e_c, column n is [-b; b_eq] (staged in vbuf), the rest zero.  A tile is
+  // materialised when panel kfirst(cb) first touches its column block (28 more live tiles otherwise)
+  constexpr int cbd = n / 16;
+  auto kfirst = [](int cb) { return (cb == cbd) ? 0 : cb; };
+  auto x_initial = [&](const int I, const int cb) {
+    d4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + grp + 4 * r, c = 16 * cb + col;
+      double v = (row == c && c < n) ? 1.0 : 0.0;
+      if (cb == cbd) v = (c == n) ? ((row < N) ? vbuf[row < N ? row : 0] : 0.0) : v;
+      t[r] = v;
+    }
+    return t;
+  };
+  lds_fence();   // the first kScratch doubles of the image are the exchange scratch from here on
+  lds_f64 *const Sblk = M;          // diagonal tile, column-major 16 x 16
+  lds_f64 *const Sinv = M + 256;    // its L^-1, column-major
+  lds_f64 *const Srcp = M + 512;    // 1 / d of the tile's rows
+  bool bad = false;
+  double rcp_panel0 = 0.0;   // (kLazy: the image is still being read during panel 0; its 1/d are stored after it)
+  static_for<0, NRB>([&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    constexpr int kValid = (N - 16 * P < 16) ? N - 16 * P : 16;
+    // (1) diagonal tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sblk[16 * col + grp + 4 * r] = C[P][P][r];
+    lds_fence();
+    double Ainv[4], nrv[4];
+    {
+      double T[16], Y[16], dmine, rmine;
+      const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
+#pragma unroll
+      for (int ip = 0; ip < 8; ++ip) {
+        const d2 t = colp[ip];
+        T[2 * ip] = t.x;
+        T[2 * ip + 1] = t.y;
+      }
+      lds_fence();
+      FCCQP_FINE(0, bad |= tile_ldl<kValid>(T, Y, dmine, rmine, col));
+      if (lane < 16) {
+        lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
+#pragma unroll
+        for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
+        Srcp[col] = rmine;
+        if (P == 0 && kLazy) rcp_panel0 = rmine;
+        else M[SH::kRcpOffset + 16 * P + col] = rmine;
+        if (P == 1 && kLazy) M[SH::kRcpOffset + col] = rcp_panel0;
+      }
+      lds_fence();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // A[i][k] = (L^-1)[i][4r + k], strictly below the diagonal (the unit diagonal is the accumulator's start)
+      const double li = Sinv[16 * (4 * r + grp) + col];
+      Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
+      nrv[r] = -Srcp[grp + 4 * r];
+    }
+    lds_fence();
+    // (2) row panel: V_pj = L^-1 C_pj (in place); Y_p = L^-1 X_p
+#pragma unroll
+    for (int J = P + 1; J < NRB; ++J) {
+      d4 t = C[P][J];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * P + 4 * r < N) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], C[P][J][r], t, 0, 0, 0);
+      C[P][J] = t;
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      if (!zero_tile(P, cb)) {
+        if (P == kfirst(cb)) X[P][cb] = x_initial(P, cb);
+        d4 t = X[P][cb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * P + 4 * r < N) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], X[P][cb][r], t, 0, 0, 0);
+        X[P][cb] = t;
+      }
+    }
+    // (3) the rows below
+#pragma unroll
+    for (int I = P + 1; I < NRB; ++I) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+        if (!zero_tile(P, cb) && P == kfirst(cb)) X[I][cb] = x_initial(I, cb);
+      if (P == 0 && kLazy) {
+#pragma unroll
+        for (int J = I; J < NRB; ++J) C[I][J] = load_tile(I, J);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (16 * P + 4 * r < N) {
+          const double aop = C[P][I][r] * nrv[r];        // A[i][k] = -(V_pi[4r + k][i] / d_{4r + k})
+#pragma unroll
+          for (int J = I; J < NRB; ++J)
+            C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            if (!zero_tile(P, cb)) X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[P][cb][r], X[I][cb], 0, 0, 0);
+        }
+      }
+    }
+  });
+  return bad;
+}
+
 // Left-looking panel LDL^T, in place in LDS.  On return M holds L below the diagonal, the
 // diagonal slots hold 1/d (0 where |d| <= DBL_MIN: Eigen's LDLT::solve rule) and dvec holds d.
 // Returns true if a pivot was zero or not finite (where Eigen's info() can fail).
@@ -528,7 +680,7 @@ __device__ __forceinline__ void p3_mfma(lds_f64 *M, lds_f64 *vbuf, const int lan
 // C0, the panel's first column, is a template parameter: every column base, the diagonal block's
 // lane window and the short-last-panel masks become constants (one instantiation per panel).
 template <class SH, int C0>
-__device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const int lane) {
+__device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const int lane, long long *fine = nullptr) {
   constexpr int N = SH::N, P = kPanel, c0 = C0;
   constexpr bool USE0 = C0 < kWave;
   constexpr bool USE1 = N > kWave;              // a second register slot exists (rows 64 + lane)
@@ -537,8 +689,11 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
   const int r0c = (row0 < N) ? row0 : N - 1;   // clamped rows: in-bounds reads for idle lanes
   const int r1c = (row1 < N) ? row1 : N - 1;
   // (b) first: the contribution of every earlier column, on the matrix cores, in place in LDS
-  if constexpr (C0 > 0) mfma_bulk_rb<SH, C0 / 16>(M, dvec, lane);
+  if constexpr (C0 > 0) FCCQP_FINE(0, (mfma_bulk_rb<SH, C0 / 16>(M, dvec, lane)));
   double T0[P], T1[P];
+#ifdef FCCQP_FINE_STAMPS
+  const long long tl_ = wall_clock64();
+#endif
   // (a) panel columns into registers
 #pragma unroll
   for (int jj = 0; jj < P; ++jj) {
@@ -547,6 +702,11 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
     T0[jj] = USE0 ? M[cb + r0c] : 0.0;
     T1[jj] = USE1 ? M[cb + r1c] : 0.0;
   }
+#ifdef FCCQP_FINE_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const long long tp_ = wall_clock64();
+  if (fine) fine[1] += tp_ - tl_;
+#endif
   // (c) factorise the panel itself, column by column.  All 16 panel rows live in one register
   // slot (64 is a multiple of 16), so the multipliers l_{c0+jj, j} of the in-panel update are
   // read straight out of the owner lanes (v_readlane) -- no LDS round trip on the critical path.
@@ -597,6 +757,10 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
     }
     d = dn; rinv = rn;
   }
+#ifdef FCCQP_FINE_STAMPS
+  const long long ts_ = wall_clock64();
+  if (fine) fine[2] += ts_ - tp_;
+#endif
   // (d) write the panel back: rows below the diagonal block take all 16 columns ...
   if constexpr (USE0) {
     if (row0 >= c0 + P && row0 < N) {
@@ -624,14 +788,18 @@ __device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const in
     }
   }
   lds_fence();
+#ifdef FCCQP_FINE_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (fine) fine[1] += wall_clock64() - ts_;
+#endif
   return bad_any;
 }
 
 template <class SH>
-__device__ __forceinline__ bool factor_lds(lds_f64 *M, lds_f64 *dvec, const int lane) {
+__device__ __forceinline__ bool factor_lds(lds_f64 *M, lds_f64 *dvec, const int lane, long long *fine = nullptr) {
   bool bad = false;
   static_for<0, (SH::N + kPanel - 1) / kPanel>([&](auto pc) {
-    bad |= factor_panel<SH, kPanel * decltype(pc)::value>(M, dvec, lane);
+    bad |= factor_panel<SH, kPanel * decltype(pc)::value>(M, dvec, lane, fine);
   });
   return bad;
 }
@@ -930,21 +1098,32 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   // (fcc_qp.cpp:159-178) and K_rho for the iterations.  Here x0 comes out of the K_rho factorisation
   // (see "presolve" below), so Q and A_eq are read from HBM exactly once and the second N^3/3 is
   // replaced by an n^3/3 one.
+#ifdef FCCQP_FINE_STAMPS
+  long long fine_k[3] = {0, 0, 0}, fine_w[3] = {0, 0, 0};   // K_rho: diagonal tiles, -, Gram MFMAs + stores; W: bulk, load/store, in-panel
+#else
+  long long *const fine_k = nullptr, *const fine_w = nullptr;
+#endif
   assemble(a.rho);
   const long long t0 = wall_clock64();
   ph_asm = t0 - t_begin;
-  if (factor_lds<SH>(M, dvec, lane)) flags |= kFlagAdmmNumerical;  // info() is not checked by the reference (cpp:68)
-  ticks = wall_clock64() - t0;
-
   {
-    // ---- P3: rho G = rho (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n] -----------------
+    // ---- P1 + P3: factorisation of K_rho with the forward solve of [E | -b; b_eq] fused in, then
+    // rho G = rho (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n] as a Gram product ----------
     double Mrow[n];
     double xc;
-    stage_rhs();
-    const long long t3 = wall_clock64();
-    p3_mfma<SH>(M, vbuf, lane, a.rho, var, Mrow, xc);
-    long long t4 = wall_clock64();
-    ph_p3 = t4 - t3;
+    long long t4;
+    {
+      constexpr int NRB = (N + 15) / 16;
+      d4 X[NRB][kWave / 16];
+      stage_rhs();
+      // info() is not checked by the reference (cpp:68)
+      if (tile_factor_forward<SH>(M, vbuf, lane, X, fine_k)) flags |= kFlagAdmmNumerical;
+      const long long t3 = wall_clock64();
+      ticks = t3 - t0;
+      gram_output<SH>(M, vbuf, lane, a.rho, var, X, Mrow, xc, fine_k);
+      t4 = wall_clock64();
+      ph_p3 = t4 - t3;
+    }
 
     // ---- presolve (fcc_qp.cpp:159-178; skipped on warm start) ----------------------------------------
     // x0 = (K^-1 r).head(n), r = [-b; b_eq].  With E = [I_n; 0], K = K_rho - rho E E^T, and the
@@ -971,7 +1150,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
         if (var >= j) M[SW::cbase(j) + var] = ((var == j) ? 1.0 : 0.0) - Mrow[j];
       lds_fence();
       const long long tw = wall_clock64();
-      bool wbad = factor_lds<SW>(M, dvec, lane);
+      bool wbad = factor_lds<SW>(M, dvec, lane, fine_w);
       const double dw = dvec[vi];
       wbad = wbad || __any(!(dw > kPresolveMinPivot));
       ticks += wall_clock64() - tw;
@@ -1028,24 +1207,29 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     int max_iter = a.max_iter;
     asm volatile("" : "+s"(max_iter));
     n_iter = max_iter;           // :78
-#pragma nounroll
-    for (int iter = 0; iter < max_iter; ++iter) {
+    // x = x_c + (rho G) w   == the KKT solve of :83-87, this lane = row `var` of rho G.  Every lane needs all
+    // of w.  Reading it back as LDS broadcasts (ds_read_b128 of two doubles into all 64 lanes: a
+    // 1-KiB return per instruction) made the four waves of a CU wait on the LDS return path: 409 ns
+    // per mat-vec.  Instead each 16-lane row takes a copy of w, 16 entries per register
+    // (Wq[lane] = w[16 q + (lane & 15)]: NQ plain ds_read_b64), and the FMA itself fetches its
+    // operand from lane l of the row (v_fmac_f64 with the DPP control row_newbcast:l, the one DPP
+    // mode the fp64 ALU has): no LDS traffic, no extra instruction (tools/dpp_bench.hip).
+    // The write of w and the reads of its copies are issued at the END of an iteration, before the exit
+    // test, which then runs in the shadow of the LDS round trip (the wave's only one per iteration).
+    constexpr int NQ = (n + 15) / 16;
+    double Wq[NQ];
+    auto exchange_w = [&]() {
       // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
       const double w = (cone_i != 0) ? (lcbar - mulc) : (xbar - mux);
       *wslot = w;
-      lds_fence();
-      // x = x_c + (rho G) w   == the KKT solve of :83-87, this lane = row `var` of rho G.  Every lane needs all
-      // of w.  Reading it back as LDS broadcasts (ds_read_b128 of two doubles into all 64 lanes: a
-      // 1-KiB return per instruction) made the four waves of a CU wait on the LDS return path: 409 ns
-      // per mat-vec.  Instead each 16-lane row takes a copy of w, 16 entries per register
-      // (Wq[lane] = w[16 q + (lane & 15)]: NQ plain ds_read_b64), and the FMA itself fetches its
-      // operand from lane l of the row (v_fmac_f64 with the DPP control row_newbcast:l, the one DPP
-      // mode the fp64 ALU has): no LDS traffic, no extra instruction (tools/dpp_bench.hip).
-      constexpr int NQ = (n + 15) / 16;
-      double Wq[NQ];
+      lds_fence();     // (one wave: its LDS operations complete in order; this is a compiler fence)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];
       lds_fence();
+    };
+    if (max_iter > 0) exchange_w();
+#pragma nounroll
+    for (int iter = 0; iter < max_iter; ++iter) {
       double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0};
       // the DPP read of a VGPR needs two wait states after a VALU write of it (the registers come
       // straight from the LDS reads, but a copy could be scheduled in between): pin them here
@@ -1075,12 +1259,13 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
         lr = x - lcbar;                   // :96
         mulc += lr;                       // :102
       }
+      exchange_w();                       // for the next iteration (harmless after the last)
       // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test
       // is one ballot instead of two wave reductions; the norms themselves (:97-98) are only
       // reported, and are reduced once after the loop.  An empty contact set has norm 0.
-      bool ok = (var_i == 0) || (fabs(xr) < eps_b);
-      ok = ok && ((cone_i == 0) || (fabs(lr) < eps_f));
-      if (__all(ok)) {
+      // (bitwise, not short-circuit: lane masks combined with scalar instructions, no branches)
+      const bool fail = ((var_i != 0) & !(fabs(xr) < eps_b)) | ((cone_i != 0) & !(fabs(lr) < eps_f));
+      if (__builtin_amdgcn_ballot_w64(fail) == 0) {
         n_iter = iter;
         break;
       }
@@ -1131,8 +1316,18 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       a.phase_ticks[3 * B + inst] = ph_p3;
       a.phase_ticks[4 * B + inst] = ph_p4;
       a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
+#ifdef FCCQP_FINE_STAMPS
+      // K_rho: bulk, load/store, in-panel; W: the same, packed as slots 6, 7 (K) and 0, 2, 3 (see tools)
+      a.phase_ticks[0 * B + inst] = fine_k[0];
+      a.phase_ticks[6 * B + inst] = fine_k[1];
+      a.phase_ticks[7 * B + inst] = fine_k[2];
+      a.phase_ticks[2 * B + inst] = fine_w[0];
+      a.phase_ticks[3 * B + inst] = fine_w[1];
+      a.phase_ticks[4 * B + inst] = fine_w[2];
+#else
       a.phase_ticks[6 * B + inst] = ph_asm;
       a.phase_ticks[7 * B + inst] = t_begin;
+#endif
     }
   }
 }

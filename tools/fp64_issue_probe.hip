@@ -80,7 +80,49 @@ void run(const char *name, double *out, long long *cyc) {
   printf("%-58s %7.2f clock64 ticks per instruction (group)\n", name, s / blocks / iters / 16);
 }
 
+// accuracy of v_rsq_f64 refined by 0, 1 and 2 Newton steps (the cone projection's reciprocal square root)
+__global__ void rsq_accuracy(const double *a, double *r0, double *r1, double *r2, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double x = a[i];
+  double r = __builtin_amdgcn_rsq(x);
+  r0[i] = r;
+  double e = fma(-x * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  r1[i] = r;
+  e = fma(-x * r, r, 1.0);
+  r = fma(0.5 * r, e, r);
+  r2[i] = r;
+}
+#include <cmath>
+#include <vector>
+#include <random>
+static void rsq_report() {
+  const int count = 1 << 20;
+  std::vector<double> a(count), h0(count), h1(count), h2(count);
+  std::mt19937_64 gen(7);
+  std::uniform_real_distribution<double> ex(-40.0, 40.0);
+  for (auto &v : a) v = std::exp2(ex(gen));
+  double *da, *d0, *d1, *d2;
+  (void)hipMalloc(&da, count * 8); (void)hipMalloc(&d0, count * 8); (void)hipMalloc(&d1, count * 8); (void)hipMalloc(&d2, count * 8);
+  (void)hipMemcpy(da, a.data(), count * 8, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(rsq_accuracy, dim3(count / 256), dim3(256), 0, 0, da, d0, d1, d2, count);
+  (void)hipMemcpy(h0.data(), d0, count * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(h1.data(), d1, count * 8, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(h2.data(), d2, count * 8, hipMemcpyDeviceToHost);
+  double m0 = 0, m1 = 0, m2 = 0;
+  for (int i = 0; i < count; ++i) {
+    const long double ref = 1.0L / sqrtl((long double)a[i]);
+    m0 = std::fmax(m0, (double)fabsl((h0[i] - ref) / ref));
+    m1 = std::fmax(m1, (double)fabsl((h1[i] - ref) / ref));
+    m2 = std::fmax(m2, (double)fabsl((h2[i] - ref) / ref));
+  }
+  printf("v_rsq_f64 max relative error over 2^20 samples: raw %.3e, one Newton step %.3e, two %.3e (eps = %.3e)\n", m0, m1, m2,
+         2.220446049250313e-16);
+}
+
 int main() {
+  rsq_report();
   double *out; long long *cyc;
   (void)hipMalloc(&out, 1024 * 64 * 8); (void)hipMalloc(&cyc, 1024 * 8);
   run<0>("v_fma_f64, 8 chains", out, cyc);

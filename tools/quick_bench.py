@@ -24,4 +24,4 @@ for kern, name in [(C.KERNEL_GENERIC, "generic"), (C.KERNEL_FUSED, "fused")]:
     print(f"{name:8s} batch={nb} {wl}: kernel ms {['%.3f' % m for m in ms]} -> {nb / min(ms) * 1e3:,.0f} solves/s; "
           f"max rel err {err.max():.2e}; dn_iter max {np.abs(it[:256] - itr).max()}; mean n_iter {it.mean():.1f}; "
           f"factor_time mean {np.mean([x.factorization_time for x in d]) * 1e6:.1f} us", flush=True)
-    print("   phases us [asm, factor, presolve-solve, P3, P4, total]:", ["%.1f" % (v * 1e6) for v in s.phase_seconds()[:7]], flush=True)
+    print("   phases us [asm, factor, presolve-solve, P3, P4, total]:", ["%.1f" % (v * 1e6) for v in s.phase_seconds()[:8]], flush=True)

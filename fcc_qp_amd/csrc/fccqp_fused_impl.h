@@ -5,44 +5,41 @@
 //   FCCQP::Solve   src/fcc_qp.cpp:114-191   FCCQP::DoADMM  src/fcc_qp.cpp:57-112
 //   projections    src/constraint_utils.cpp:5-65      Eigen LDLT call sites fcc_qp.cpp:68,86,161,174
 //
-// Why it looks the way it does (numbers from tools/microbench.hip on MI355X, gfx950):
-//   * v_fma_f64 issues every ~4 cycles and one wave with one dependent chain already saturates
-//     its SIMD: occupancy buys nothing for the arithmetic.
-//   * only 256 of the 512 registers per lane are VALU-addressable (the rest are AGPRs), so the
-//     98x98 KKT cannot live in registers: it lives in LDS (packed lower triangle, 39 KB) and is
-//     factorised in place; registers hold one 16-column panel at a time.
-//   * an operand every lane needs (same-address ds_read) costs 2 LDS cycles per double per CU
-//     (the return path moves 16 B x 64 lanes for 16 useful bytes); v_readlane costs ~9 cycles per
-//     double.  Broadcast-fed VALU loops (lane = row, or lane = right-hand side) were the first
-//     version of the factorisation's bulk update and of P3 and were LDS-bound at half the FMA rate.
-//   * fp64 MFMA (v_mfma_f64_16x16x4) has the same 78.6 TFLOP/s peak as the fp64 VALU, so it buys
-//     no flops -- but it takes its operands ONE ELEMENT PER LANE (a plain lane-distinct
-//     ds_read_b64, no broadcast), it leaves no lanes idle in triangular panels, and an
-//     accumulator tile can be fed straight back as the next product's B operand.  The two real
-//     contractions of the path, the (rows x c0)(c0 x 16) bulk update of a panel and the
-//     98 x 98 triangular solve with 64 right-hand sides of P3, therefore run on the matrix cores;
-//     everything sequential (in-panel pivots, the single-vector presolve, the 60 x 60 mat-vec of
-//     an ADMM iteration) stays on the VALU.
+// Why it looks the way it does (numbers from tools/fp64_issue_probe.hip and tools/lane_ops_probe.hip on MI355X):
+//   * one wave per SIMD: a v_fma_f64 issues every ~5.8 cycles whether or not it depends on the previous
+//     one, a v_mfma_f64_16x16x4 (1024 FMAs) every ~72-84 cycles: the matrix pipe is ~25 % cheaper per
+//     flop than the VALU (same 78.6 TFLOP/s peak), runs beside it, and -- what matters -- takes its
+//     operands ONE ELEMENT PER LANE and hands its result tile back as the next product's operand.
+//   * an operand every lane needs costs an LDS broadcast (2 LDS cycles per double per CU), a
+//     v_readlane pair (~9 cycles per double) -- or nothing: the fp64 ALU's one DPP mode, row_newbcast,
+//     lets an FMA read lane k of its 16-lane row.  Every sequential piece of the path (diagonal-tile
+//     elimination, tile inverse, the mat-vec of an ADMM iteration) is laid out so that the operand it
+//     needs sits in a lane of the same row.
+//   * 512 registers per lane (256 VGPR + 256 AGPR, MFMA reads and writes both) hold the whole upper
+//     triangle of the 98 x 98 KKT matrix as 28 accumulator tiles plus the right-hand-side tiles; LDS
+//     (39 KB per QP) holds the assembled image once, then exchange scratch, rho G and the presolve factor.
 //
 // Phases, N = n + m (walking shape: n = 60, m = 38, N = 98):
 //   P0  assemble the lower triangle of K_rho = [[Q + rho I, A^T],[A, 0]] in LDS, ONCE (coalesced
 //       16-byte reads of Q and A_eq; fcc_qp.cpp:146-150,62-64).
-//   P1  factorise K_rho (fcc_qp.cpp:68): unpivoted LDL^T in natural order, left-looking by panels
-//       of 16 columns: the contribution of all earlier columns is one MFMA product per 16 x 16 row
-//       block, in place in LDS (mfma_bulk); then lane l owns rows l and 64+l of the panel in
-//       registers and the 16 pivots are eliminated with v_readlane-broadcast multipliers
-//       (factor_panel).  L overwrites K; 1/d_j (Eigen's pseudo-inverse rule) is kept on the diagonal.
-//   P3  G = (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n]: blocked forward / D^-1 /
-//       backward substitution of the 98 x 64 block [e_0 .. e_{n-1} | -b; b_eq | 0] held in MFMA
-//       accumulator tiles (p3_mfma), then through LDS to the layout of P4: lane l holds row l
-//       of rho G and x_c[l].
+//   P1  factorise K_rho (fcc_qp.cpp:68) with the forward solve of [e_0 .. e_{n-1} | -b; b_eq] fused in
+//       (tile_factor_forward): unpivoted, natural order, right-looking by 16 x 16 register tiles in
+//       the form U^T D U, in which every trailing update contracts over the ROWS of the panel's
+//       tiles -- both MFMA operands are accumulator registers, nothing is read from or written to
+//       LDS except the 16 x 16 diagonal tile, which takes a trip to a column-per-lane layout to be
+//       eliminated and inverted with DPP-fed FMAs (tile_ldl).  Pivot rule: 1/d_j = 0 for
+//       |d_j| <= DBL_MIN (Eigen's pseudo-inverse rule in LDLT::solve).
+//   P3  rho G = rho (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n] as the Gram product
+//       Y^T D^-1 Y of the forward result (gram_output), then through LDS to the layout of P4: a lane
+//       holds one row of rho G and one entry of x_c.  The tiles of W = I - rho G stay in registers.
 //   Pw  presolve, skipped on warm start (fcc_qp.cpp:159-178): the reference's x0 = (K^-1 [-b; b_eq])
 //       .head(n) without a factorisation of K: x0 = (I - rho G)^-1 x_c (Woodbury; see the kernel
-//       body), an n x n panel LDL^T with the same code.  One assembly, one pass over HBM.
+//       body); W is factorised by the same register tiles, its factor written to LDS for the two
+//       triangular sweeps of the single right-hand side.  One assembly, one pass over HBM.
 //   P4  ADMM iterations (fcc_qp.cpp:79-110): the KKT solve of an iteration is
 //       x = x_c + (rho G) w,  w = x_bar - mu_x (lambda_c segment overwritten, fcc_qp.cpp:82):
-//       a 60x60 mat-vec with w broadcast through LDS; projections, residuals, dual update and the
-//       exit test are per-lane work plus one ballot.
+//       a 60x60 mat-vec (DPP-fed FMAs, one LDS exchange of w); projections, residuals, dual update
+//       and the exit test are per-lane work, quad_perm moves inside a contact and one ballot.
 //   P5  epilogue metrics (fcc_qp.cpp:184-186) and write-back of z and the warm-start state.
 //
 // Pivot order: natural (no pivoting).  For rho > 0, Q >= 0 and A_eq of full row rank K_rho is
@@ -62,7 +59,6 @@ namespace fccqp {
 namespace fused {
 
 constexpr int kWave = 64;
-constexpr int kPanel = 16;
 // presolve: smallest pivot of W = I - rho G (eigenvalues in (0, 1]) still taken as non-singular.
 // A pivot p amplifies the ~1e-16 error of rho G by 1/p; below this the instance goes to the COD
 // fallback, whose minimum-norm solution is what the reference returns for a singular K.
@@ -87,9 +83,9 @@ __device__ __forceinline__ void lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// Development aid: -DFCCQP_FINE_STAMPS splits the factorisation time (100 MHz ticks, summed over the
-// panels of both factorisations) into bulk update / panel load + store / in-panel steps and reports
-// them in phase slots 6, 7 and 0 (tools/quick_bench.py prints the slots).
+// Development aid: -DFCCQP_FINE_STAMPS reports (100 MHz ticks, per QP) the time in the diagonal tiles of
+// K_rho (phase slot 0) and of W (slot 2) and in the Gram product with its stores (slot 7); tools/quick_bench.py
+// prints the slots.
 #ifdef FCCQP_FINE_STAMPS
 #define FCCQP_FINE(slot, expr) do { const long long t_ = wall_clock64(); expr; if (fine) fine[slot] += wall_clock64() - t_; } while (0)
 #else
@@ -206,7 +202,8 @@ struct Packed {
   // keeps the reciprocal pivots of all (padded) rows behind both the scratch and the later rho G image.
   static constexpr int kScratch = 544;
   static constexpr int kRowsPadded = 16 * ((N + 15) / 16);
-  static constexpr int kMat = (kPacked > kScratch + kRowsPadded) ? kPacked : kScratch + kRowsPadded;
+  // (small shapes: 2 kScratch leaves room for the presolve's packed n x n factor in front of its scratch)
+  static constexpr int kMat = (kPacked > 2 * kScratch) ? kPacked : 2 * kScratch;
   static constexpr int kNp = (N + 1) & ~1;
 };
 
@@ -246,103 +243,29 @@ struct Shape : Packed<N_VARS + N_EQ> {
 };
 
 
-// Bulk update of a panel on the matrix cores.  For the 16 columns c0..c0+15 and every row >= c0,
-//   K[i][j] -= sum_{q < c0} (L[i][q] d_q) L[j][q]
-// is a (rows x c0) by (c0 x 16) product.  v_mfma_f64_16x16x4_f64 has the same peak as the fp64
-// VALU, so this is not about flops: on the VALU the update runs lane = row with the L[j][q]
-// operands broadcast out of LDS (one 1-KiB ds_read_b128 return per two FMAs, and 20-60 % of the
-// lanes idle in the triangular panels), while the MFMA takes its operands one element per lane
-// (A[i][k] = lane i + 16 k, B[k][n] = lane n + 16 k: one ds_read_b64 each, no broadcast) and only
-// the row blocks at or below the panel are touched.  The tiles are read from and written back to
-// the panel's own columns in LDS, so the rest of factor_panel (load, in-panel step, write-back)
-// is unchanged.  Layouts (cdna_hip_programming.md): C/D col = lane & 15, row = (lane >> 4) + 4 r.
 using d4 = double __attribute__((ext_vector_type(4)));
-// RB0 = c0 / 16, the first row block that holds rows >= c0, is a template parameter: with a
-// run-time `rb >= rb0` around every tile the compiler turns the fetch-then-MFMA structure back into
-// load / wait / MFMA triples behind branches.
-template <class SH, int RB0>
-__device__ __forceinline__ void mfma_bulk_rb(lds_f64 *M, const lds_f64 *dvec, const int lane) {
-  constexpr int N = SH::N, NRB = (N + 15) / 16;
-  constexpr int rb0 = RB0, c0 = 16 * RB0;
-  const int col = lane & 15, grp = lane >> 4;
-  const int j = (c0 + col < N) ? c0 + col : N - 1;       // this lane's panel column (clamped)
-  const int cbj = SH::cbase(j);
-  d4 acc[NRB];
-#pragma unroll
-  for (int rb = 0; rb < NRB; ++rb) {
-    if (rb >= rb0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[rb][r] = M[cbj + 16 * rb + grp + 4 * r];   // rows past N-1: garbage rows
-    }
-  }
-  // four columns q0..q0+3 per step (k = grp picks this lane's column); the operands of the next
-  // step are fetched before the MFMAs of the current one (c0 is a multiple of 16: steps pair up)
-  struct Ops { double b, nd, av[NRB]; };
-  auto fetch = [&](const int q0, Ops &o) {
-    const int cq = SH::cbase(q0 + grp);
-    o.b = M[cq + c0 + col];                              // B[k][n] = L[c0 + n][q0 + k]
-    o.nd = -dvec[q0 + grp];
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-      if (rb >= rb0) o.av[rb] = M[cq + 16 * rb + col];   // A[i][k] = L[16 rb + i][q0 + k]  (x -d_q below)
-  };
-  auto apply = [&](const Ops &o) {
-#pragma unroll
-    for (int rb = 0; rb < NRB; ++rb)
-      if (rb >= rb0) acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.av[rb] * o.nd, o.b, acc[rb], 0, 0, 0);
-  };
-  {
-    // fully unrolled (c0 is a template constant): the column bases become per-lane constants + offsets
-    Ops oa, ob;
-    fetch(0, oa);
-#pragma unroll
-    for (int q0 = 0; q0 < c0; q0 += 8) {
-      fetch(q0 + 4, ob);
-      apply(oa);
-      if (q0 + 8 < c0) fetch(q0 + 8, oa);
-      apply(ob);
-    }
-  }
-  lds_fence();
-#pragma unroll
-  for (int rb = 0; rb < NRB; ++rb) {
-    if (rb >= rb0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * rb + grp + 4 * r;
-        // on or below the diagonal of an existing column only (above it the address belongs to the
-        // previous column's tail); which tiles can violate which condition is known statically
-        bool ok = true;
-        if (rb == rb0) ok = ok && (row >= c0 + col);
-        if (16 * rb + 15 >= N) ok = ok && (row < N);
-        if (c0 + 15 >= N) ok = ok && (c0 + col < N);
-        if (ok) M[cbj + row] = acc[rb][r];
-      }
-    }
-  }
-  lds_fence();
-}
 
-
-// rho G = rho Y^T D^-1 Y (n x n) and x_c (row n of the product) from the forward result Y (tiles X) and the
-// reciprocal pivots rd; rho G goes through LDS (over the dead matrix image) to Mrow = row `grow` of rho G.
+// rho G = rho Y^T D^-1 Y (n x n) and x_c = G[0:n, n] from the forward result Y (tiles X) and the reciprocal pivots
+// (left in LDS by tile_factor_forward).  rho G goes through LDS (over the dead matrix image) to Mrow = row
+// `grow` of rho G; the upper tiles of W = I - rho G (identity-padded to whole tiles) stay in registers for
+// the presolve (tile_factor_store).
 template <class SH>
 __device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho, const int grow,
-                                            const d4 (&X)[(SH::N + 15) / 16][kWave / 16], double (&Mrow)[SH::n], double &xc,
-                                            long long *fine = nullptr) {
-  constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NCB = kWave / 16;
+                                            const d4 (&X)[(SH::N + 15) / 16][kWave / 16],
+                                            d4 (&Wt)[(SH::n + 15) / 16][(SH::n + 15) / 16], double (&Mrow)[SH::n],
+                                            double &xc, long long *fine = nullptr) {
+  constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NW = (n + 15) / 16;
   const int col = lane & 15, grp = lane >> 4;
 #ifdef FCCQP_FINE_STAMPS
   const long long tg_ = wall_clock64();
 #endif
   // ---- G = Y^T D^-1 Y with Y = L^-1 [E | r] (the forward result) -------------------------------------
-  // (K_rho^-1)[0:n, 0:n] = E^T L^-T D^-1 L^-1 E: instead of the backward sweep with L^T -- 364 MFMAs
-  // chained through the row blocks, each with an operand out of LDS -- the product of the forward
-  // result with itself: register r of tile Y[K][cb] is at once the B operand (B[k][n] = Y[4r+k][n])
-  // and, for the transposed factor, the A operand (A[i][k] = Y[4r+k][i]) of k-step r, so all
-  // operands come out of the accumulators, the tile products are independent of each other, only
-  // the lower tiles (J <= I) are computed and Y's zero tiles (rows above the unit entries) are
-  // skipped: 236 MFMAs for the walking shape.  Row n of the product is x_c.
+  // (K_rho^-1)[0:n, 0:n] = E^T L^-T D^-1 L^-1 E: instead of a backward sweep with L^T -- MFMAs chained
+  // through the row blocks -- the product of the forward result with itself: register r of tile
+  // Y[K][cb] is at once the B operand (B[k][n] = Y[4r+k][n]) and, for the transposed factor, the A
+  // operand (A[i][k] = Y[4r+k][i]) of k-step r, so all operands come out of the accumulators, the tile
+  // products are independent of each other, only the upper tiles (J >= I) are computed and Y's zero
+  // tiles (rows above the unit entries) are skipped.  Column n of the product is x_c.
   constexpr int cbd = n / 16;                            // the column block that holds the dense column [-b; b_eq]
   auto kmin = [](int cb) { return (cb == cbd) ? 0 : cb; };   // first row block in which Y[.][cb] is not all zero
   // 1/d per tile row, left behind the rho G image by tile_factor_forward (kept there rather than in 56
@@ -354,36 +277,36 @@ __device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int
     for (int r = 0; r < 4; ++r) rd[K][r] = M[SH::kRcpOffset + 16 * K + grp + 4 * r];
   lds_fence();
 #pragma unroll
-  for (int I = 0; I < NCB; ++I) {
-    if (16 * I <= n) {                                   // (tiles whose rows are all beyond row n are never used)
-      d4 Gt[NCB];
+  for (int I = 0; I < NW; ++I) {
+    d4 Gt[cbd + 1];
 #pragma unroll
-      for (int J = 0; J < NCB; ++J) Gt[J] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int J = I; J <= cbd; ++J) Gt[J] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int K = 0; K < NRB; ++K) {
-        if (K >= kmin(I)) {
+    for (int K = 0; K < NRB; ++K) {
+      if (K >= kmin(I)) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (4 * (4 * K + r) < N) {
-              const double aop = X[K][I][r] * rd[K][r];
+        for (int r = 0; r < 4; ++r) {
+          if (4 * (4 * K + r) < N) {
+            const double aop = X[K][I][r] * rd[K][r];
 #pragma unroll
-              for (int J = 0; J <= I; ++J)
-                if (K >= kmin(J)) Gt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[K][J][r], Gt[J], 0, 0, 0);
-            }
+            for (int J = I; J <= cbd; ++J)
+              if (K >= kmin(J)) Gt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[K][J][r], Gt[J], 0, 0, 0);
           }
         }
       }
+    }
 #pragma unroll
-      for (int J = 0; J <= I; ++J) {
+    for (int J = I; J <= cbd; ++J) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * I + grp + 4 * r, c = 16 * J + col;     // Gt[J][r] = (K_rho^-1)[row][c]
-          if (row < n && c < n) {
-            M[row * n + c] = rho * Gt[J][r];
-            if (J != I) M[c * n + row] = rho * Gt[J][r];               // the mirror tile
-          }
-          if (row == n && c < n) vbuf[c] = Gt[J][r];                   // x_c
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + grp + 4 * r, c = 16 * J + col;     // Gt[J][r] = (K_rho^-1)[row][c]
+        const double g = rho * Gt[J][r];
+        if (row < n && c < n) {
+          M[row * n + c] = g;
+          if (J != I) M[c * n + row] = g;                            // the mirror tile
         }
+        if (J == cbd && c == n && row < n) vbuf[row] = Gt[J][r];     // x_c
+        if (J < NW) Wt[I][J][r] = (row < n && c < n) ? (((row == c) ? 1.0 : 0.0) - g) : ((row == c) ? 1.0 : 0.0);
       }
     }
   }
@@ -425,10 +348,10 @@ __device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int
 //       U_pj / Y_p) come straight out of the accumulators -- no operand is ever read from LDS, no tile is
 //       ever written back to it, and the panel's tiles are dead once step (3) is done (the factor itself
 //       is not kept: G = Y^T D^-1 Y needs only Y and D).
-// Against the left-looking LDS version (factor_lds + the forward sweep of p3_mfma) this removes the panel
-// loads / stores (10 us per QP), the per-k-step operand fetches and the 98-row-high in-panel updates with
-// their v_readlane pairs (the serial part shrinks to the 16 x 16 diagonal tiles).  Same elimination
-// order (natural, unpivoted), same pivot rules as factor_panel.
+// Against the left-looking in-LDS panel factorisation of rounds 1-2a (and its separate forward sweep) this
+// removes the panel loads / stores (10 us per QP), the per-k-step operand fetches and the 98-row-high
+// in-panel updates with their v_readlane pairs (the serial part shrinks to the 16 x 16 diagonal tiles).
+// Same elimination order (natural, unpivoted) and the same pivot rules.
 __device__ __forceinline__ double pivot_inverse(double dd) {   // Eigen's LDLT::solve drops |d| <= DBL_MIN
   const double r = fast_rcp(dd);
   return (fabs(dd) > DBL_MIN) ? r : 0.0;
@@ -525,7 +448,9 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
   static_assert(n < kWave, "n + 1 right-hand sides in 64 columns");
 
   const int col = lane & 15, grp = lane >> 4;
-  auto zero_tile = [](int K, int cb) { return K < cb && cb != n / 16; };   // see p3_mfma
+  // tile X[K][cb] is still all zero while every unit entry of column block cb lies below row block K; the
+  // block that holds the dense column [-b; b_eq] is the exception
+  auto zero_tile = [](int K, int cb) { return K < cb && cb != n / 16; };
   // ---- tiles of the upper triangle out of the packed image (element (i, j), i <= j, is packed (j, i)) -----
   // Row panel 0 is loaded here; the other tiles are loaded when panel 0 first updates them (28 tiles +
   // the diagonal-tile work of panel 0 do not fit the register file).  The exchange scratch of the
@@ -668,143 +593,95 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
   return bad;
 }
 
-// Left-looking panel LDL^T, in place in LDS.  On return M holds L below the diagonal, the
-// diagonal slots hold 1/d (0 where |d| <= DBL_MIN: Eigen's LDLT::solve rule) and dvec holds d.
-// Returns true if a pivot was zero or not finite (where Eigen's info() can fail).
-//
-// Written for instruction count: with one wave per SIMD every instruction -- FMA, readlane,
-// cndmask, scalar address arithmetic alike -- takes a 4-cycle issue slot, so the panel code is
-// compiled twice (USE0: rows < 64 take part / only rows >= 64 do) instead of branching inside,
-// columns are addressed by a running offset, loads are unmasked (rows above the diagonal pick
-// up garbage that is never stored) and the panel is written back once at the end.
-// C0, the panel's first column, is a template parameter: every column base, the diagonal block's
-// lane window and the short-last-panel masks become constants (one instantiation per panel).
-template <class SH, int C0>
-__device__ __forceinline__ bool factor_panel(lds_f64 *M, lds_f64 *dvec, const int lane, long long *fine = nullptr) {
-  constexpr int N = SH::N, P = kPanel, c0 = C0;
-  constexpr bool USE0 = C0 < kWave;
-  constexpr bool USE1 = N > kWave;              // a second register slot exists (rows 64 + lane)
-  static_assert(USE0 || USE1, "panel past the matrix");
-  const int row0 = lane, row1 = kWave + lane;
-  const int r0c = (row0 < N) ? row0 : N - 1;   // clamped rows: in-bounds reads for idle lanes
-  const int r1c = (row1 < N) ? row1 : N - 1;
-  // (b) first: the contribution of every earlier column, on the matrix cores, in place in LDS
-  if constexpr (C0 > 0) FCCQP_FINE(0, (mfma_bulk_rb<SH, C0 / 16>(M, dvec, lane)));
-  double T0[P], T1[P];
-#ifdef FCCQP_FINE_STAMPS
-  const long long tl_ = wall_clock64();
-#endif
-  // (a) panel columns into registers
-#pragma unroll
-  for (int jj = 0; jj < P; ++jj) {
-    const int j = (c0 + jj < N) ? c0 + jj : N - 1;
-    const int cb = SH::cbase(j);
-    T0[jj] = USE0 ? M[cb + r0c] : 0.0;
-    T1[jj] = USE1 ? M[cb + r1c] : 0.0;
-  }
-#ifdef FCCQP_FINE_STAMPS
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const long long tp_ = wall_clock64();
-  if (fine) fine[1] += tp_ - tl_;
-#endif
-  // (c) factorise the panel itself, column by column.  All 16 panel rows live in one register
-  // slot (64 is a multiple of 16), so the multipliers l_{c0+jj, j} of the in-panel update are
-  // read straight out of the owner lanes (v_readlane) -- no LDS round trip on the critical path.
-  const int lane0 = c0 & (kWave - 1);
-  const int rel = lane - lane0;            // position of this lane's diagonal-block row in the panel
-  bool bad_any = false;
-  double dmine = 1.0, rmine = 0.0;
-  const int ncol = (N - c0 < P) ? N - c0 : P;   // columns that exist (the last panel may be short)
-  // the pivot of column k+1 is broadcast and inverted as soon as column k+1 has received step k's
-  // update (the first one issued), so the reciprocal chain of the next step hides under the rest
-  // of this step's FMAs.  rinv is 0 for a pivot with |d| <= DBL_MIN: Eigen's LDLT leaves the column
-  // below a zero pivot alone (it is zero if the matrix is consistent, e.g. a duplicated equality
-  // row) and its solve() drops the pivot (pseudo-inverse rule); scaling by 0 does both.
-  auto pinv = [](double dd) { const double r = fast_rcp(dd); return (fabs(dd) > DBL_MIN) ? r : 0.0; };
-  double d = bcast_lane(USE0 ? T0[0] : T1[0], lane0);
-  double rinv = pinv(d);
-#pragma unroll
-  for (int k = 0; k < P; ++k) {
-    // zero, infinite or NaN pivot (class mask: sNaN|qNaN|-inf|-0|+0|+inf); columns past N in a
-    // short last panel hold garbage that is computed on (no branch) but neither judged nor stored
-    bad_any |= (k < ncol) & __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
-    dmine = (rel == k) ? d : dmine;
-    rmine = (rel == k) ? rinv : rmine;
-    const double a0 = T0[k], a1 = T1[k];
-    if constexpr (USE0) T0[k] = a0 * rinv;
-    if constexpr (USE1) T1[k] = a1 * rinv;
-    const double lsrc = USE0 ? T0[k] : T1[k];
-    // rank-1 update of the panel columns to the right:  T[i][jj] -= a_i * l_{c0+jj, j}.
-    // The scalar for column jj+1 is read (v_readlane pair) before the FMAs of column jj, which
-    // fills the wait states between a v_readlane and the VALU that consumes its SGPRs; the empty
-    // asm keeps this order -- left alone the scheduler separates the two FMAs of a scalar and
-    // spills every scalar to a VGPR lane (v_writelane + s_nop) to read it back later.
-    double lcur = (k + 1 < P) ? bcast_lane(lsrc, lane0 + k + 1) : 0.0;
-    double dn = d, rn = rinv;
-#pragma unroll
-    for (int jj = k + 1; jj < P; ++jj) {
-      double lnext = (jj + 1 < P) ? bcast_lane(lsrc, lane0 + jj + 1) : 0.0;
-      if constexpr (USE0) T0[jj] = fma(-a0, lcur, T0[jj]);
-      if constexpr (USE1) T1[jj] = fma(-a1, lcur, T1[jj]);
-      if constexpr (USE0 && USE1) asm volatile("" : "+v"(T0[jj]), "+v"(T1[jj]), "+s"(lnext));
-      else if constexpr (USE0) asm volatile("" : "+v"(T0[jj]), "+s"(lnext));
-      else asm volatile("" : "+v"(T1[jj]), "+s"(lnext));
-      if (jj == k + 1) {  // column k+1 is final: look ahead
-        dn = bcast_lane(USE0 ? T0[jj] : T1[jj], lane0 + jj);
-        rn = pinv(dn);
-      }
-      lcur = lnext;
-    }
-    d = dn; rinv = rn;
-  }
-#ifdef FCCQP_FINE_STAMPS
-  const long long ts_ = wall_clock64();
-  if (fine) fine[2] += ts_ - tp_;
-#endif
-  // (d) write the panel back: rows below the diagonal block take all 16 columns ...
-  if constexpr (USE0) {
-    if (row0 >= c0 + P && row0 < N) {
-#pragma unroll
-      for (int k = 0; k < P; ++k)
-        if (k < ncol) M[SH::cbase(c0 + k) + row0] = T0[k];
-    }
-  }
-  if constexpr (USE1) {
-    if (row1 >= c0 + P && row1 < N) {
-#pragma unroll
-      for (int k = 0; k < P; ++k)
-        if (k < ncol) M[SH::cbase(c0 + k) + row1] = T1[k];
-    }
-  }
-  // ... the diagonal block's own rows only what lies strictly below the diagonal, plus d, 1/d
-  {
-    const int rowd = USE0 ? row0 : row1;
-    if (rel >= 0 && rel < ncol) {
-#pragma unroll
-      for (int k = 0; k < P - 1; ++k)
-        if (rel > k) M[SH::cbase(c0 + k) + rowd] = USE0 ? T0[k] : T1[k];
-      dvec[rowd] = dmine;
-      M[SH::cbase(rowd) + rowd] = rmine;
-    }
-  }
-  lds_fence();
-#ifdef FCCQP_FINE_STAMPS
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (fine) fine[1] += wall_clock64() - ts_;
-#endif
-  return bad_any;
-}
-
+// W = U^T D U by register tiles (the presolve, see fused_kernel), same scheme as tile_factor_forward without
+// right-hand sides; the factor is WRITTEN to LDS in the packed layout solve_lds reads (L = U^T below the
+// diagonal, 1/d in the diagonal slots, d in dvec).  Returns true if a pivot was zero or not finite.
+// The exchange scratch sits behind the packed n x n image.
 template <class SH>
-__device__ __forceinline__ bool factor_lds(lds_f64 *M, lds_f64 *dvec, const int lane, long long *fine = nullptr) {
+__device__ __forceinline__ bool tile_factor_store(lds_f64 *M, lds_f64 *dvec, const int lane,
+                                                  d4 (&C)[(SH::n + 15) / 16][(SH::n + 15) / 16], long long *fine = nullptr) {
+  using SW = typename SH::Reduced;
+  constexpr int n = SH::n, NW = (n + 15) / 16;
+  constexpr int kOff = (SW::kPacked + 1) & ~1;
+  static_assert(kOff + SH::kScratch <= SH::kMat, "exchange scratch behind the packed W");
+  const int col = lane & 15, grp = lane >> 4;
+  lds_f64 *const Sblk = M + kOff;
+  lds_f64 *const Sinv = Sblk + 256;
+  lds_f64 *const Srcp = Sblk + 512;
   bool bad = false;
-  static_for<0, (SH::N + kPanel - 1) / kPanel>([&](auto pc) {
-    bad |= factor_panel<SH, kPanel * decltype(pc)::value>(M, dvec, lane, fine);
+  static_for<0, NW>([&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    constexpr int kValid = (n - 16 * P < 16) ? n - 16 * P : 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Sblk[16 * col + grp + 4 * r] = C[P][P][r];
+    lds_fence();
+    double Ainv[4], rv[4];
+    {
+      double T[16], Y[16], dmine, rmine;
+      const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
+#pragma unroll
+      for (int ip = 0; ip < 8; ++ip) {
+        const d2 t = colp[ip];
+        T[2 * ip] = t.x;
+        T[2 * ip + 1] = t.y;
+      }
+      lds_fence();
+      FCCQP_FINE(0, bad |= tile_ldl<kValid>(T, Y, dmine, rmine, col));
+      if (lane < 16) {
+        lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
+#pragma unroll
+        for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
+        Srcp[col] = rmine;
+        // column 16 P + col of L (tile_ldl left T = -L), its d and 1/d
+        if (col < kValid) {
+          const int jcol = 16 * P + col, cb = SW::cbase(jcol);
+          dvec[jcol] = dmine;
+          M[cb + jcol] = rmine;
+#pragma unroll
+          for (int i = 1; i < kValid; ++i)
+            if (i > col) M[cb + 16 * P + i] = -T[i];
+        }
+      }
+      lds_fence();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double li = Sinv[16 * (4 * r + grp) + col];
+      Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
+      rv[r] = Srcp[grp + 4 * r];
+    }
+    lds_fence();
+#pragma unroll
+    for (int J = P + 1; J < NW; ++J) {
+      d4 t = C[P][J];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * P + 4 * r < n) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], C[P][J][r], t, 0, 0, 0);
+      C[P][J] = t;
+      // L[16 J + col][16 P + row] = U_pj[row][col] = V_pj[row][col] / d_row
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jrow = 16 * P + grp + 4 * r, irow = 16 * J + col;
+        if (irow < n) M[SW::cbase(jrow) + irow] = t[r] * rv[r];      // (jrow < n: P < J)
+      }
+    }
+#pragma unroll
+    for (int I = P + 1; I < NW; ++I) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double aop = C[P][I][r] * -rv[r];
+#pragma unroll
+        for (int J = I; J < NW; ++J)
+          C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
+      }
+    }
   });
+  lds_fence();
   return bad;
 }
 
-// x := (L D L^T)^-1 x with M as left by factor_lds; x0/x1 are this lane's rows lane / 64+lane.
+// x := (L D L^T)^-1 x with M as left by tile_factor_store (L below the diagonal, 1/d in the diagonal slots);
+// x0/x1 are this lane's rows lane / 64+lane.
 // Column-oriented forward and backward substitution.  The only dependent chain is
 // v_readlane(x_k) -> fma; the L operands of four steps are fetched ahead of it, unconditionally
 // (clamped rows, masked by a select) and through running column offsets, so a step is ~11
@@ -1099,7 +976,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   // (see "presolve" below), so Q and A_eq are read from HBM exactly once and the second N^3/3 is
   // replaced by an n^3/3 one.
 #ifdef FCCQP_FINE_STAMPS
-  long long fine_k[3] = {0, 0, 0}, fine_w[3] = {0, 0, 0};   // K_rho: diagonal tiles, -, Gram MFMAs + stores; W: bulk, load/store, in-panel
+  long long fine_k[3] = {0, 0, 0}, fine_w[3] = {0, 0, 0};   // K_rho: diagonal tiles, -, Gram product; W: diagonal tiles
 #else
   long long *const fine_k = nullptr, *const fine_w = nullptr;
 #endif
@@ -1112,6 +989,8 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     double Mrow[n];
     double xc;
     long long t4;
+    constexpr int NW = (n + 15) / 16;
+    d4 Wt[NW][NW];   // upper tiles of W = I - rho G, from the Gram product to the presolve
     {
       constexpr int NRB = (N + 15) / 16;
       d4 X[NRB][kWave / 16];
@@ -1120,7 +999,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       if (tile_factor_forward<SH>(M, vbuf, lane, X, fine_k)) flags |= kFlagAdmmNumerical;
       const long long t3 = wall_clock64();
       ticks = t3 - t0;
-      gram_output<SH>(M, vbuf, lane, a.rho, var, X, Mrow, xc, fine_k);
+      gram_output<SH>(M, vbuf, lane, a.rho, var, X, Wt, Mrow, xc, fine_k);
       t4 = wall_clock64();
       ph_p3 = t4 - t3;
     }
@@ -1144,13 +1023,10 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     if (!a.warm_start) {
       using SW = typename SH::Reduced;
       flags |= kFlagPresolveRan;
-      // W, packed lower, over the rho G image in LDS (row `var` of rho G is in registers by now)
-#pragma unroll
-      for (int j = 0; j < n; ++j)
-        if (var >= j) M[SW::cbase(j) + var] = ((var == j) ? 1.0 : 0.0) - Mrow[j];
-      lds_fence();
+      // W arrives as register tiles from the Gram product; its factor goes to LDS (over the rho G image:
+      // row `var` of rho G is in registers by now) for the two triangular sweeps
       const long long tw = wall_clock64();
-      bool wbad = factor_lds<SW>(M, dvec, lane, fine_w);
+      bool wbad = tile_factor_store<SH>(M, dvec, lane, Wt, fine_w);
       const double dw = dvec[vi];
       wbad = wbad || __any(!(dw > kPresolveMinPivot));
       ticks += wall_clock64() - tw;

@@ -441,8 +441,64 @@ __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], doubl
   return bad;
 }
 
+// P0: the upper triangle of K_rho = [[Q + rho I, A^T],[A, 0]] (fcc_qp.cpp:146-150,62-64) from global memory
+// straight into accumulator-layout tiles: C[I][J][r] = K_rho[i][j], i = 16 I + (lane >> 4) + 4 r, j = 16 J + (lane & 15).
+// Only Q[a][b] with a >= b is read (like Eigen's Lower LDLT), so element (i, j), i <= j, comes from row j of Q
+// (or row j - n of A_eq): the 16 lanes of a lane-row read 16 rows, the 4 lane-rows 4 consecutive entries,
+// and the four loads r = 0 .. 3 of a tile finish each 128-byte piece of a row.  Rows >= n are the zero
+// block; rows / columns >= N pad the last tile with the identity.  All loads are issued before the first
+// value is used: the first panel's diagonal tile is factorised while the rest is still in flight.
+template <class SH, class TIN>
+__device__ __forceinline__ void load_kkt_tiles(const TIN *__restrict__ Q, const TIN *__restrict__ A, const double rho,
+                                               const int lane, d4 (&C)[(SH::N + 15) / 16][(SH::N + 15) / 16]) {
+  constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16;
+  const int col = lane & 15, grp = lane >> 4;
+  TIN raw[NRB][NRB][4];
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+    if (16 * I < n) {
+#pragma unroll
+      for (int J = I; J < NRB; ++J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + grp + 4 * r, j = 16 * J + col;
+          const int lo = (I == J && j < i) ? j : i, hi = (I == J && j < i) ? i : j;
+          const int loc = (lo < n) ? lo : n - 1;                  // clamped: in-bounds reads for masked entries
+          const int hic = (hi < N) ? hi : N - 1;
+          if (16 * J + 15 < n) {
+            raw[I][J][r] = Q[hic * n + loc];
+          } else if (16 * J >= n) {
+            raw[I][J][r] = A[(hic - n) * n + loc];
+          } else {
+            const TIN *src = (hic < n) ? Q + hic * n : A + (hic - n) * n;
+            raw[I][J][r] = src[loc];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+#pragma unroll
+    for (int J = I; J < NRB; ++J) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * I + grp + 4 * r, j = 16 * J + col;
+        const int lo = (I == J && j < i) ? j : i, hi = (I == J && j < i) ? i : j;
+        double v = (i == j && i >= N) ? 1.0 : 0.0;
+        if (16 * I < n) {
+          const double q = (double)raw[I][J][r] + ((I == J && i == j) ? rho : 0.0);
+          v = (lo < n && hi < N) ? q : v;
+        }
+        C[I][J][r] = v;
+      }
+    }
+  }
+}
+
 template <class SH>
 __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, const int lane,
+                                                    d4 (&C)[(SH::N + 15) / 16][(SH::N + 15) / 16],
                                                     d4 (&X)[(SH::N + 15) / 16][kWave / 16], long long *fine = nullptr) {
   constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NCB = kWave / 16;
   static_assert(n < kWave, "n + 1 right-hand sides in 64 columns");
@@ -451,42 +507,6 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
   // tile X[K][cb] is still all zero while every unit entry of column block cb lies below row block K; the
   // block that holds the dense column [-b; b_eq] is the exception
   auto zero_tile = [](int K, int cb) { return K < cb && cb != n / 16; };
-  // ---- tiles of the upper triangle out of the packed image (element (i, j), i <= j, is packed (j, i)) -----
-  // Row panel 0 is loaded here; the other tiles are loaded when panel 0 first updates them (28 tiles +
-  // the diagonal-tile work of panel 0 do not fit the register file).  The exchange scratch of the
-  // diagonal tiles is the start of the packed image -- columns 0 .. 15, dead once row panel 0 is in
-  // registers -- so the rest of the image stays readable through panel 0.  (Tiny shapes, whose whole
-  // image is smaller than the scratch, load everything up front.)
-  d4 C[NRB][NRB];
-  auto load_tile = [&](const int I, const int J) {
-    d4 t;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 16 * I + grp + 4 * r, j = 16 * J + col;
-      const int ic = (i < N) ? i : N - 1, jc = (j < N) ? j : N - 1;
-      double v;
-      if (J == I) {
-        const int lo = (ic < jc) ? ic : jc, hi = (ic < jc) ? jc : ic;
-        v = M[SH::cbase(lo) + hi];
-        if (16 * I + 15 >= N) v = (i < N && j < N) ? v : ((i == j) ? 1.0 : 0.0);   // identity padding
-      } else {
-        v = M[SH::cbase(ic) + jc];
-        if (16 * J + 15 >= N) v = (j < N) ? v : 0.0;
-        if (16 * I + 15 >= N) v = (i < N) ? v : 0.0;
-      }
-      t[r] = v;
-    }
-    return t;
-  };
-  constexpr int kScratch = SH::kScratch;
-  constexpr bool kLazy = NRB > 1 && SH::cbase(16 < N ? 16 : 0) + 16 >= kScratch;
-#pragma unroll
-  for (int I = 0; I < NRB; ++I) {
-    if (I == 0 || !kLazy) {
-#pragma unroll
-      for (int J = I; J < NRB; ++J) C[I][J] = load_tile(I, J);
-    }
-  }
   // right-hand sides: column c < n is e_c, column n is [-b; b_eq] (staged in vbuf), the rest zero.  A tile is
   // materialised when panel kfirst(cb) first touches its column block (28 more live tiles otherwise)
   constexpr int cbd = n / 16;
@@ -502,12 +522,10 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
     }
     return t;
   };
-  lds_fence();   // the first kScratch doubles of the image are the exchange scratch from here on
-  lds_f64 *const Sblk = M;          // diagonal tile, column-major 16 x 16
+  lds_f64 *const Sblk = M;          // exchange scratch: diagonal tile, column-major 16 x 16
   lds_f64 *const Sinv = M + 256;    // its L^-1, column-major
   lds_f64 *const Srcp = M + 512;    // 1 / d of the tile's rows
   bool bad = false;
-  double rcp_panel0 = 0.0;   // (kLazy: the image is still being read during panel 0; its 1/d are stored after it)
   static_for<0, NRB>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
     constexpr int kValid = (N - 16 * P < 16) ? N - 16 * P : 16;
@@ -532,9 +550,7 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
 #pragma unroll
         for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
         Srcp[col] = rmine;
-        if (P == 0 && kLazy) rcp_panel0 = rmine;
-        else M[SH::kRcpOffset + 16 * P + col] = rmine;
-        if (P == 1 && kLazy) M[SH::kRcpOffset + col] = rcp_panel0;
+        M[SH::kRcpOffset + 16 * P + col] = rmine;
       }
       lds_fence();
     }
@@ -572,10 +588,6 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb)
         if (!zero_tile(P, cb) && P == kfirst(cb)) X[I][cb] = x_initial(I, cb);
-      if (P == 0 && kLazy) {
-#pragma unroll
-        for (int J = I; J < NRB; ++J) C[I][J] = load_tile(I, J);
-      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (16 * P + 4 * r < N) {
@@ -886,71 +898,6 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   int flags = 0;
   long long ticks = 0;
 
-  // P0: lower triangle of [[Q + rho I, A^T],[A, 0]] into LDS; Q and A_eq are read front to back,
-  // 16 bytes per lane (fcc_qp.cpp:146-150; only Q[i][j], i >= j, is used, like Eigen's Lower LDLT)
-  // Each lane owns one column pair (2l, 2l+1), l = lane & 31, for the whole assembly, so the LDS
-  // column offsets are computed once; lanes 0-31 walk the rows from the top, lanes 32-63 from the
-  // bottom, which pairs a short row of the triangle with a long one (about half the lanes carry
-  // data each trip) and reads only the lower triangle of Q from HBM.
-  auto assemble = [&](double rho) {
-    using T2 = TIN __attribute__((ext_vector_type(2)));
-    if constexpr (n % 2 == 0) {
-      const int half = lane >> 5, l = lane & 31, j0 = 2 * l;
-      const int jc = (j0 < n) ? j0 : 0;
-      const int cb0 = SH::cbase(jc), cb1 = SH::cbase(jc + 1);
-      // all global loads first, unconditionally (idle lanes re-read a pair another lane needs), so that they
-      // are in flight together: a load inside the per-row branch is waited for before the next
-      // row's load is even issued (30 serialised HBM round trips per assembly)
-      constexpr int mh = (m + 1) / 2;
-      // lanes above the diagonal re-read the row's first pair (same cache line): only the lower
-      // triangle of Q comes from HBM.  n even: element (row, j) is pair-aligned for even j
-      const T2 *Q2 = reinterpret_cast<const T2 *>(Q);
-      const T2 *A2 = reinterpret_cast<const T2 *>(A);
-      T2 vq[n / 2], va[mh];   // widened (float storage) only at the store: no second register image
-#pragma unroll
-      for (int it = 0; it < n / 2; ++it) {
-        const int row = half ? (n - 1 - it) : it;
-        vq[it] = Q2[(row * n + ((j0 < n && j0 <= row) ? j0 : 0)) >> 1];
-      }
-#pragma unroll
-      for (int it = 0; it < mh; ++it) {
-        const int r = half ? (it + mh) : it;
-        va[it] = A2[(((r < m) ? r : 0) * n + jc) >> 1];
-      }
-#pragma unroll
-      for (int it = 0; it < n / 2; ++it) {
-        const int row = half ? (n - 1 - it) : it;
-        if (j0 < n && j0 <= row) {
-          M[cb0 + row] = (double)vq[it].x + ((row == j0) ? rho : 0.0);
-          if (j0 + 1 <= row) M[cb1 + row] = (double)vq[it].y + ((row == j0 + 1) ? rho : 0.0);
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < mh; ++it) {
-        const int r = half ? (it + mh) : it;
-        if (j0 < n && r < m) {
-          M[cb0 + n + r] = (double)va[it].x;
-          M[cb1 + n + r] = (double)va[it].y;
-        }
-      }
-    } else {
-      for (int e = lane; e < n * n; e += kWave) {
-        const int i = e / n, j = e - i * n;
-        if (i >= j) M[SH::cbase(j) + i] = (double)Q[e] + ((i == j) ? rho : 0.0);
-      }
-      for (int e = lane; e < m * n; e += kWave) { const int r = e / n; M[SH::cbase(e - r * n) + n + r] = (double)A[e]; }
-    }
-    // zero block: rows >= n of columns >= n (column j holds rows j..N-1: at most m <= 64 of them)
-    {
-      int cb = SH::cbase(n);
-#pragma unroll 4
-      for (int j = n; j < N; ++j) {
-        if (j + lane < N) M[cb + j + lane] = 0.0;
-        cb += SH::cstep(j);
-      }
-    }
-    lds_fence();
-  };
   // [-b; b_eq] (fcc_qp.cpp:149-150) into vbuf[0..N)
   auto stage_rhs = [&]() {
     const double *bp = fresh(bq), *ep = fresh(beq);
@@ -980,9 +927,6 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 #else
   long long *const fine_k = nullptr, *const fine_w = nullptr;
 #endif
-  assemble(a.rho);
-  const long long t0 = wall_clock64();
-  ph_asm = t0 - t_begin;
   {
     // ---- P1 + P3: factorisation of K_rho with the forward solve of [E | -b; b_eq] fused in, then
     // rho G = rho (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n] as a Gram product ----------
@@ -993,10 +937,15 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     d4 Wt[NW][NW];   // upper tiles of W = I - rho G, from the Gram product to the presolve
     {
       constexpr int NRB = (N + 15) / 16;
-      d4 X[NRB][kWave / 16];
+      d4 C[NRB][NRB], X[NRB][kWave / 16];
+      load_kkt_tiles<SH, TIN>(Q, A, a.rho, lane, C);
       stage_rhs();
+      // (the loads are still in flight here: the phase boundary is nominal, the wait falls into the
+      // factorisation's first use of each tile)
+      const long long t0 = wall_clock64();
+      ph_asm = t0 - t_begin;
       // info() is not checked by the reference (cpp:68)
-      if (tile_factor_forward<SH>(M, vbuf, lane, X, fine_k)) flags |= kFlagAdmmNumerical;
+      if (tile_factor_forward<SH>(M, vbuf, lane, C, X, fine_k)) flags |= kFlagAdmmNumerical;
       const long long t3 = wall_clock64();
       ticks = t3 - t0;
       gram_output<SH>(M, vbuf, lane, a.rho, var, X, Wt, Mrow, xc, fine_k);

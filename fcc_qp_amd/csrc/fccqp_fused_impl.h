@@ -181,6 +181,19 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
   return inside ? v : (polar ? 0.0 : side);
 }
 
+__device__ __forceinline__ double pivot_inverse(double dd) {   // Eigen's LDLT::solve drops |d| <= DBL_MIN
+  const double r = fast_rcp(dd);
+  return (fabs(dd) > DBL_MIN) ? r : 0.0;
+}
+// a / d from r = pivot_inverse(d): the product a r corrected by one residual step, i.e. the correctly rounded
+// quotient in all but rare cases and EXACTLY 1 for a == d.  That is what makes a duplicated equality row
+// eliminate to an exactly zero column and an exactly zero pivot, as it does with the reference's true
+// division (Eigen LDLT: A21 /= pivot), instead of a pivot of rounding-error size whose reciprocal
+// wrecks the solve; r == 0 (dropped pivot) stays 0.
+__device__ __forceinline__ double pivot_quotient(double a, double d, double r) {
+  const double q = a * r;
+  return fma(fma(-d, q, a), r, q);
+}
 // (fast_rcp above is also the pivot reciprocal of the factorisation: <= 1 ulp from the correctly
 // rounded quotient, a third of the dependent-instruction chain of an IEEE division.)
 
@@ -227,6 +240,21 @@ struct Shape : Packed<N_VARS + N_EQ> {
   static_assert(n * n + KKT::kRowsPadded <= kMat, "rho G (n x n, row-major) and 1/d fit over the dead factor");
   // where tile_factor_forward leaves 1/d_row for gram_output
   static constexpr int kRcpOffset = (n * n > KKT::kScratch) ? n * n : KKT::kScratch;
+  // Bordering.  16 x 16 tiles waste most of a last row block that holds only N % 16 rows (walking shape:
+  // 2 of 16, and a fifth of all MFMAs touch it).  When those last rows lie in the zero block and the
+  // right-hand-side tile column that carries [-b; b_eq] has free columns for them, the tiles factorise
+  // only the leading N1 = N - kBorder rows, the border columns K_rho[0:N1, N1:N] ride along as extra
+  // right-hand sides, and the last kBorder pivots are the LDL^T of the small Schur complement read off
+  // the Gram product (gram_output) -- the same elimination order, the same pivots.
+  static constexpr int kBorder =
+      (N % 16 != 0 && N - N % 16 >= n && (n % 16) + (N % 16) <= 15 && N % 16 <= 3) ? N % 16 : 0;
+  static constexpr int N1 = N - kBorder;
+  static constexpr int kTileRows = 16 * ((N1 + 15) / 16);
+  // LDS staging of the border columns (kBorder x kTileRows, behind the reciprocal pivots) and, later, of
+  // the Gram columns n .. n + kBorder (rows 0 .. n + kBorder)
+  static constexpr int kBorderOffset = kRcpOffset + KKT::kRowsPadded;
+  static_assert(kBorderOffset + kBorder * kTileRows <= kMat && kBorderOffset + (n + kBorder + 1) * (kBorder + 1) <= kMat,
+                "border staging fits behind the image");
   // Lane <-> variable map of the ADMM loop.  Contact c owns lanes 4c, 4c+1, 4c+2 (x, y, z): a lane
   // gets the three components of its contact force with quad_perm DPP moves instead of an LDS round
   // trip per iteration.  The other variables fill the fourth lane of those quads, then the lanes past
@@ -245,28 +273,31 @@ struct Shape : Packed<N_VARS + N_EQ> {
 
 using d4 = double __attribute__((ext_vector_type(4)));
 
-// rho G = rho Y^T D^-1 Y (n x n) and x_c = G[0:n, n] from the forward result Y (tiles X) and the reciprocal pivots
-// (left in LDS by tile_factor_forward).  rho G goes through LDS (over the dead matrix image) to Mrow = row
-// `grow` of rho G; the upper tiles of W = I - rho G (identity-padded to whole tiles) stay in registers for
-// the presolve (tile_factor_store).
+// rho G = rho (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n] from the forward result Y (tiles X) and the
+// reciprocal pivots (left in LDS by tile_factor_forward).  rho G goes through LDS (over the dead matrix
+// image) to Mrow = row `grow` of rho G; the upper tiles of W = I - rho G (identity-padded to whole tiles)
+// stay in registers for the presolve (tile_factor_store).  Returns true if one of the bordered pivots
+// (Shape::kBorder) was zero or not finite.
 template <class SH>
-__device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho, const int grow,
-                                            const d4 (&X)[(SH::N + 15) / 16][kWave / 16],
+__device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho, const int grow,
+                                            const d4 (&X)[(SH::N1 + 15) / 16][kWave / 16],
                                             d4 (&Wt)[(SH::n + 15) / 16][(SH::n + 15) / 16], double (&Mrow)[SH::n],
                                             double &xc, long long *fine = nullptr) {
-  constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NW = (n + 15) / 16;
+  constexpr int N = SH::N1, n = SH::n, NRB = (N + 15) / 16, NW = (n + 15) / 16, NB = SH::kBorder;
   const int col = lane & 15, grp = lane >> 4;
 #ifdef FCCQP_FINE_STAMPS
   const long long tg_ = wall_clock64();
 #endif
-  // ---- G = Y^T D^-1 Y with Y = L^-1 [E | r] (the forward result) -------------------------------------
-  // (K_rho^-1)[0:n, 0:n] = E^T L^-T D^-1 L^-1 E: instead of a backward sweep with L^T -- MFMAs chained
-  // through the row blocks -- the product of the forward result with itself: register r of tile
-  // Y[K][cb] is at once the B operand (B[k][n] = Y[4r+k][n]) and, for the transposed factor, the A
-  // operand (A[i][k] = Y[4r+k][i]) of k-step r, so all operands come out of the accumulators, the tile
-  // products are independent of each other, only the upper tiles (J >= I) are computed and Y's zero
-  // tiles (rows above the unit entries) are skipped.  Column n of the product is x_c.
-  constexpr int cbd = n / 16;                            // the column block that holds the dense column [-b; b_eq]
+  // ---- Gram product P = Y^T D^-1 Y with Y = L^-1 [E | r | B] (the forward result) ----------------------
+  // (K1^-1)[0:n, 0:n] = E^T L^-T D^-1 L^-1 E (K1: the rows the tiles eliminated): instead of a backward
+  // sweep with L^T -- MFMAs chained through the row blocks -- the product of the forward result with
+  // itself: register r of tile Y[K][cb] is at once the B operand (B[k][n] = Y[4r+k][n]) and, for the
+  // transposed factor, the A operand (A[i][k] = Y[4r+k][i]) of k-step r, so all operands come out of
+  // the accumulators, the tile products are independent of each other, only the upper tiles (J >= I)
+  // are computed and Y's zero tiles (rows above the unit entries) are skipped.  Column n of the product
+  // is K1^-1 r, columns n+1 .. n+kBorder are K1^-1 B.
+  constexpr int cbd = n / 16;                            // the column block that holds the dense columns
+  constexpr int NI = (NB > 0) ? cbd + 1 : NW;            // row blocks of the product that are needed
   auto kmin = [](int cb) { return (cb == cbd) ? 0 : cb; };   // first row block in which Y[.][cb] is not all zero
   // 1/d per tile row, left behind the rho G image by tile_factor_forward (kept there rather than in 56
   // registers across the factorisation)
@@ -276,11 +307,11 @@ __device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int
 #pragma unroll
     for (int r = 0; r < 4; ++r) rd[K][r] = M[SH::kRcpOffset + 16 * K + grp + 4 * r];
   lds_fence();
+  d4 Gt[NI][cbd + 1];
 #pragma unroll
-  for (int I = 0; I < NW; ++I) {
-    d4 Gt[cbd + 1];
+  for (int I = 0; I < NI; ++I) {
 #pragma unroll
-    for (int J = I; J <= cbd; ++J) Gt[J] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int J = I; J <= cbd; ++J) Gt[I][J] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int K = 0; K < NRB; ++K) {
       if (K >= kmin(I)) {
@@ -290,22 +321,133 @@ __device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int
             const double aop = X[K][I][r] * rd[K][r];
 #pragma unroll
             for (int J = I; J <= cbd; ++J)
-              if (K >= kmin(J)) Gt[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[K][J][r], Gt[J], 0, 0, 0);
+              if (K >= kmin(J)) Gt[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[K][J][r], Gt[I][J], 0, 0, 0);
           }
         }
       }
     }
+  }
+  // ---- the bordered rows: K_rho = [[K1, B],[B^T, 0]] (fused_kernel keeps them in the zero block), so
+  //   S = -B^T K1^-1 B (kBorder x kBorder) carries the last kBorder pivots of the same elimination order,
+  //   (K_rho^-1)[0:n,0:n] = (K1^-1)[0:n,0:n] + Z S^-1 Z^T with Z = (K1^-1 B)[0:n],
+  //   x_c = u - Z x2,  u = (K1^-1 r1)[0:n],  x2 = S^-1 (r2 - B^T K1^-1 r1).
+  // Everything on the right is in columns n .. n+kBorder of the product: they go through LDS so that each
+  // lane can pick up the entries of its own rows and column.
+  bool bad = false;
+  double corr_r[NI][4][NB > 0 ? NB : 1];   // (Z S^-1)[row][b] for this lane's rows of row block I
+  double x2[NB > 0 ? NB : 1];
+  lds_f64 *const Eb = M + SH::kBorderOffset;     // Eb[row * (NB + 1) + k] = P[row][n + k]
+  if constexpr (NB > 0) {
 #pragma unroll
-    for (int J = I; J <= cbd; ++J) {
+    for (int I = 0; I < NI; ++I) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + grp + 4 * r, c = 16 * J + col;     // Gt[J][r] = (K_rho^-1)[row][c]
-        const double g = rho * Gt[J][r];
+        const int row = 16 * I + grp + 4 * r, c = 16 * cbd + col;
+        if (c >= n && c <= n + NB && row <= n + NB) Eb[row * (NB + 1) + (c - n)] = Gt[I][cbd][r];
+      }
+    }
+    lds_fence();
+    // S = -P[n+1.., n+1..] (symmetric; lower part from the upper tile), its LDL^T with the pivot rules of tile_ldl,
+    // S^-1 and x2 -- a handful of scalar operations, done by every lane
+    double Sm[NB][NB], Sinv[NB][NB], tvec[NB];
+#pragma unroll
+    for (int aa = 0; aa < NB; ++aa) {
+      tvec[aa] = vbuf[N + aa] - Eb[n * (NB + 1) + 1 + aa];          // r2 - B^T K1^-1 r1  (P[n][n+1+a], upper part)
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) {
+        const int lo = (aa < bb) ? aa : bb, hi = (aa < bb) ? bb : aa;
+        Sm[aa][bb] = -Eb[(n + 1 + lo) * (NB + 1) + 1 + hi];
+      }
+    }
+    // in place, lower triangle only: unit lower L below the diagonal, d on it
+    double dinv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const double d = Sm[k][k];
+      bad |= __builtin_amdgcn_class(d, 0x3 | 0x4 | 0x20 | 0x40 | 0x200);
+      dinv[k] = pivot_inverse(d);
+      double lk[NB];
+#pragma unroll
+      for (int i = k + 1; i < NB; ++i) lk[i] = pivot_quotient(Sm[i][k], d, dinv[k]);
+#pragma unroll
+      for (int i = k + 1; i < NB; ++i)
+#pragma unroll
+        for (int j = k + 1; j <= i; ++j) Sm[i][j] = fma(-lk[i], Sm[j][k], Sm[i][j]);   // (column k still unscaled)
+#pragma unroll
+      for (int i = k + 1; i < NB; ++i) Sm[i][k] = lk[i];
+    }
+    // S^-1 = L^-T D^-1 L^-1, column by column (unit vectors through the two sweeps)
+#pragma unroll
+    for (int cI = 0; cI <= NB; ++cI) {               // cI == NB: the right-hand side tvec -> x2
+      double y[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) y[i] = (cI == NB) ? tvec[i] : ((i == cI) ? 1.0 : 0.0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int k = 0; k < i; ++k) y[i] -= Sm[i][k] * y[k];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) y[i] *= dinv[i];
+#pragma unroll
+      for (int i = NB - 1; i >= 0; --i)
+#pragma unroll
+        for (int k = i + 1; k < NB; ++k) y[i] -= Sm[k][i] * y[k];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        if (cI == NB) x2[i] = y[i];
+        else Sinv[i][cI] = y[i];
+      }
+    }
+#pragma unroll
+    for (int I = 0; I < NI; ++I) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + grp + 4 * r;
+        double zr[NB];
+#pragma unroll
+        for (int aa = 0; aa < NB; ++aa) zr[aa] = Eb[((row <= n + NB) ? row : 0) * (NB + 1) + 1 + aa];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          double acc = 0.0;
+#pragma unroll
+          for (int aa = 0; aa < NB; ++aa) acc += zr[aa] * Sinv[aa][bb];
+          corr_r[I][r][bb] = acc;
+        }
+        // x_c for the lanes that hold column n of the product
+        if (16 * cbd + col == n && row < n) {
+          double v = Gt[I][cbd][r];
+#pragma unroll
+          for (int aa = 0; aa < NB; ++aa) v -= zr[aa] * x2[aa];
+          vbuf[row] = v;
+        }
+      }
+    }
+  }
+  lds_fence();
+#pragma unroll
+  for (int I = 0; I < NW; ++I) {
+#pragma unroll
+    for (int J = I; J <= cbd; ++J) {
+      double zc[NB > 0 ? NB : 1];
+      if constexpr (NB > 0) {
+        const int c = 16 * J + col;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) zc[bb] = Eb[((c < n) ? c : 0) * (NB + 1) + 1 + bb];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + grp + 4 * r, c = 16 * J + col;     // Gt[I][J][r] = (K1^-1)[row][c]
+        double gv = Gt[I][J][r];
+        if constexpr (NB > 0) {
+#pragma unroll
+          for (int bb = 0; bb < NB; ++bb) gv += corr_r[I][r][bb] * zc[bb];
+        }
+        const double g = rho * gv;
         if (row < n && c < n) {
           M[row * n + c] = g;
           if (J != I) M[c * n + row] = g;                            // the mirror tile
         }
-        if (J == cbd && c == n && row < n) vbuf[row] = Gt[J][r];     // x_c
+        if (NB == 0 && J == cbd && c == n && row < n) vbuf[row] = Gt[I][J][r];     // x_c
         if (J < NW) Wt[I][J][r] = (row < n && c < n) ? (((row == c) ? 1.0 : 0.0) - g) : ((row == c) ? 1.0 : 0.0);
       }
     }
@@ -333,6 +475,7 @@ __device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int
     for (int jj = 0; jj < n; ++jj) Mrow[jj] = isvar ? M[lr * n + jj] : 0.0;
   }
   lds_fence();
+  return bad;
 }
 
 // ---- K_rho = U^T D U by 16 x 16 tiles held in registers, with the forward solve fused in ---------------
@@ -352,10 +495,6 @@ __device__ __forceinline__ void gram_output(lds_f64 *M, lds_f64 *vbuf, const int
 // removes the panel loads / stores (10 us per QP), the per-k-step operand fetches and the 98-row-high
 // in-panel updates with their v_readlane pairs (the serial part shrinks to the 16 x 16 diagonal tiles).
 // Same elimination order (natural, unpivoted) and the same pivot rules.
-__device__ __forceinline__ double pivot_inverse(double dd) {   // Eigen's LDLT::solve drops |d| <= DBL_MIN
-  const double r = fast_rcp(dd);
-  return (fabs(dd) > DBL_MIN) ? r : 0.0;
-}
 template <int K>
 __device__ __forceinline__ double row_bcast(double v) {   // lane K of this lane's 16-lane row
   int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xf, 0xf, true);
@@ -389,7 +528,7 @@ __device__ __forceinline__ void tile_steps(double (&T)[16], double d, double rin
     dmine = (c == K) ? d : dmine;
     rmine = (c == K) ? rinv : rmine;
     if constexpr (K < 15) {
-      const double negm = (c > K) ? -(T[K] * rinv) : 0.0;
+      const double negm = (c > K) ? -pivot_quotient(T[K], d, rinv) : 0.0;
       // steps 12 .. 14 have fewer than two other updates between the write of T[i] by step K-1 and its
       // DPP read here
       if constexpr (K >= 12) asm volatile("s_nop 1" : "+v"(T[K + 1]));
@@ -450,8 +589,8 @@ __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], doubl
 // value is used: the first panel's diagonal tile is factorised while the rest is still in flight.
 template <class SH, class TIN>
 __device__ __forceinline__ void load_kkt_tiles(const TIN *__restrict__ Q, const TIN *__restrict__ A, const double rho,
-                                               const int lane, d4 (&C)[(SH::N + 15) / 16][(SH::N + 15) / 16]) {
-  constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16;
+                                               const int lane, d4 (&C)[(SH::N1 + 15) / 16][(SH::N1 + 15) / 16]) {
+  constexpr int N = SH::N1, n = SH::n, NRB = (N + 15) / 16;   // (the rows the tiles eliminate: Shape::kBorder)
   const int col = lane & 15, grp = lane >> 4;
   TIN raw[NRB][NRB][4];
 #pragma unroll
@@ -498,9 +637,9 @@ __device__ __forceinline__ void load_kkt_tiles(const TIN *__restrict__ Q, const 
 
 template <class SH>
 __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, const int lane,
-                                                    d4 (&C)[(SH::N + 15) / 16][(SH::N + 15) / 16],
-                                                    d4 (&X)[(SH::N + 15) / 16][kWave / 16], long long *fine = nullptr) {
-  constexpr int N = SH::N, n = SH::n, NRB = (N + 15) / 16, NCB = kWave / 16;
+                                                    d4 (&C)[(SH::N1 + 15) / 16][(SH::N1 + 15) / 16],
+                                                    d4 (&X)[(SH::N1 + 15) / 16][kWave / 16], long long *fine = nullptr) {
+  constexpr int N = SH::N1, n = SH::n, NRB = (N + 15) / 16, NCB = kWave / 16;   // N: the rows eliminated by tiles
   static_assert(n < kWave, "n + 1 right-hand sides in 64 columns");
 
   const int col = lane & 15, grp = lane >> 4;
@@ -517,7 +656,14 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * I + grp + 4 * r, c = 16 * cb + col;
       double v = (row == c && c < n) ? 1.0 : 0.0;
-      if (cb == cbd) v = (c == n) ? ((row < N) ? vbuf[row < N ? row : 0] : 0.0) : v;
+      if (cb == cbd) {
+        v = (c == n) ? ((row < N) ? vbuf[row < N ? row : 0] : 0.0) : v;
+        if constexpr (SH::kBorder > 0) {   // columns n+1 .. n+kBorder: the border columns of K_rho (staged by the caller)
+          const int bc = (c > n && c <= n + SH::kBorder) ? c - n - 1 : 0;
+          const double bv = M[SH::kBorderOffset + bc * SH::kTileRows + row];
+          v = (c > n && c <= n + SH::kBorder) ? bv : v;
+        }
+      }
       t[r] = v;
     }
     return t;
@@ -908,6 +1054,18 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     vbuf[lane] = vb;
     lds_fence();
     if (lane < m) vbuf[n + lane] = ve;        // n + lane < N <= kVbuf
+    // the border columns K_rho[0:N1, N1 + b] = A_eq[N1 + b - n][0:n] (then zeros): Shape::kBorder
+    if constexpr (SH::kBorder > 0) {
+      TIN bcv[SH::kBorder];
+#pragma unroll
+      for (int bb = 0; bb < SH::kBorder; ++bb) bcv[bb] = A[(SH::N1 + bb - n) * n + (isnat ? lane : 0)];
+#pragma unroll
+      for (int bb = 0; bb < SH::kBorder; ++bb) {
+        lds_f64 *bp_ = M + SH::kBorderOffset + bb * SH::kTileRows;
+        bp_[lane] = isnat ? (double)bcv[bb] : 0.0;
+        if (kWave + lane < SH::kTileRows) bp_[kWave + lane] = 0.0;
+      }
+    }
     lds_fence();
   };
 
@@ -936,7 +1094,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     constexpr int NW = (n + 15) / 16;
     d4 Wt[NW][NW];   // upper tiles of W = I - rho G, from the Gram product to the presolve
     {
-      constexpr int NRB = (N + 15) / 16;
+      constexpr int NRB = (SH::N1 + 15) / 16;
       d4 C[NRB][NRB], X[NRB][kWave / 16];
       load_kkt_tiles<SH, TIN>(Q, A, a.rho, lane, C);
       stage_rhs();
@@ -948,7 +1106,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       if (tile_factor_forward<SH>(M, vbuf, lane, C, X, fine_k)) flags |= kFlagAdmmNumerical;
       const long long t3 = wall_clock64();
       ticks = t3 - t0;
-      gram_output<SH>(M, vbuf, lane, a.rho, var, X, Wt, Mrow, xc, fine_k);
+      if (gram_output<SH>(M, vbuf, lane, a.rho, var, X, Wt, Mrow, xc, fine_k)) flags |= kFlagAdmmNumerical;
       t4 = wall_clock64();
       ph_p3 = t4 - t3;
     }

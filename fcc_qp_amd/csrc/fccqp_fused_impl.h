@@ -1134,6 +1134,9 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       // row `var` of rho G is in registers by now) for the two triangular sweeps
       const long long tw = wall_clock64();
       bool wbad = tile_factor_store<SH>(M, dvec, lane, Wt, fine_w);
+#ifdef FCCQP_FINE_STAMPS
+      fine_w[1] = wall_clock64() - tw;       // the whole factorisation of W
+#endif
       const double dw = dvec[vi];
       wbad = wbad || __any(!(dw > kPresolveMinPivot));
       ticks += wall_clock64() - tw;

@@ -586,15 +586,15 @@ __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], doubl
 // (or row j - n of A_eq): the 16 lanes of a lane-row read 16 rows, the 4 lane-rows 4 consecutive entries,
 // and the four loads r = 0 .. 3 of a tile finish each 128-byte piece of a row.  Rows >= n are the zero
 // block; rows / columns >= N pad the last tile with the identity.  All loads are issued before the first
-// value is used: the first panel's diagonal tile is factorised while the rest is still in flight.
-template <class SH, class TIN>
-__device__ __forceinline__ void load_kkt_tiles(const TIN *__restrict__ Q, const TIN *__restrict__ A, const double rho,
-                                               const int lane, d4 (&C)[(SH::N1 + 15) / 16][(SH::N1 + 15) / 16]) {
+// value is used (issue_kkt_loads, then convert_kkt_tiles): the first panel's diagonal tile is factorised
+// while the rest is still in flight.
+template <class SH, class TIN, int I0, int I1>
+__device__ __forceinline__ void issue_kkt_loads(const TIN *__restrict__ Q, const TIN *__restrict__ A, const int lane,
+                                                TIN (&raw)[(SH::N1 + 15) / 16][(SH::N1 + 15) / 16][4]) {
   constexpr int N = SH::N1, n = SH::n, NRB = (N + 15) / 16;   // (the rows the tiles eliminate: Shape::kBorder)
   const int col = lane & 15, grp = lane >> 4;
-  TIN raw[NRB][NRB][4];
 #pragma unroll
-  for (int I = 0; I < NRB; ++I) {
+  for (int I = I0; I < I1; ++I) {
     if (16 * I < n) {
 #pragma unroll
       for (int J = I; J < NRB; ++J) {
@@ -616,6 +616,12 @@ __device__ __forceinline__ void load_kkt_tiles(const TIN *__restrict__ Q, const 
       }
     }
   }
+}
+template <class SH, class TIN>
+__device__ __forceinline__ void convert_kkt_tiles(const TIN (&raw)[(SH::N1 + 15) / 16][(SH::N1 + 15) / 16][4], const double rho,
+                                                  const int lane, d4 (&C)[(SH::N1 + 15) / 16][(SH::N1 + 15) / 16]) {
+  constexpr int N = SH::N1, n = SH::n, NRB = (N + 15) / 16;
+  const int col = lane & 15, grp = lane >> 4;
 #pragma unroll
   for (int I = 0; I < NRB; ++I) {
 #pragma unroll
@@ -1044,25 +1050,30 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   int flags = 0;
   long long ticks = 0;
 
-  // [-b; b_eq] (fcc_qp.cpp:149-150) into vbuf[0..N)
-  auto stage_rhs = [&]() {
-    const double *bp = fresh(bq), *ep = fresh(beq);
-    // both loads before the first LDS store: with the fence between them they were two dependent
-    // HBM round trips
-    const double vb = isnat ? -bp[lane] : 0.0;
-    const double ve = (lane < m) ? ep[lane < m ? lane : 0] : 0.0;
-    vbuf[lane] = vb;
-    lds_fence();
-    if (lane < m) vbuf[n + lane] = ve;        // n + lane < N <= kVbuf
-    // the border columns K_rho[0:N1, N1 + b] = A_eq[N1 + b - n][0:n] (then zeros): Shape::kBorder
+  // [-b; b_eq] (fcc_qp.cpp:149-150) into vbuf[0..N), and the border columns K_rho[0:N1, N1 + b] =
+  // A_eq[N1 + b - n][0:n] (then zeros; Shape::kBorder) into their LDS staging area.  The global loads are
+  // issued between the tile loads of row panel 0 and the rest (rhs_fetch) and stored after all of them
+  // (rhs_store): memory returns in order, so a wait for a load issued behind the 88 tile loads would wait
+  // for all of them, and the first diagonal tile could not be factorised while the matrix is in flight.
+  double rhs_b = 0.0, rhs_e = 0.0;
+  TIN rhs_border[SH::kBorder > 0 ? SH::kBorder : 1];
+  auto rhs_fetch = [&]() {   // unconditional (clamped) loads: no branch, no wait in front of the tile loads
+    rhs_b = bq[isnat ? lane : 0];
+    rhs_e = beq[(lane < m) ? lane : 0];
     if constexpr (SH::kBorder > 0) {
-      TIN bcv[SH::kBorder];
 #pragma unroll
-      for (int bb = 0; bb < SH::kBorder; ++bb) bcv[bb] = A[(SH::N1 + bb - n) * n + (isnat ? lane : 0)];
+      for (int bb = 0; bb < SH::kBorder; ++bb) rhs_border[bb] = A[(SH::N1 + bb - n) * n + (isnat ? lane : 0)];
+    }
+  };
+  auto rhs_store = [&]() {
+    vbuf[lane] = isnat ? -rhs_b : 0.0;
+    lds_fence();
+    if (lane < m) vbuf[n + lane] = rhs_e;        // n + lane < N <= kVbuf
+    if constexpr (SH::kBorder > 0) {
 #pragma unroll
       for (int bb = 0; bb < SH::kBorder; ++bb) {
         lds_f64 *bp_ = M + SH::kBorderOffset + bb * SH::kTileRows;
-        bp_[lane] = isnat ? (double)bcv[bb] : 0.0;
+        bp_[lane] = isnat ? (double)rhs_border[bb] : 0.0;
         if (kWave + lane < SH::kTileRows) bp_[kWave + lane] = 0.0;
       }
     }
@@ -1096,8 +1107,14 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     {
       constexpr int NRB = (SH::N1 + 15) / 16;
       d4 C[NRB][NRB], X[NRB][kWave / 16];
-      load_kkt_tiles<SH, TIN>(Q, A, a.rho, lane, C);
-      stage_rhs();
+      // row panel 0 first, then the small vectors, then the rest: what the first panel needs arrives first,
+      // and the wait for the vectors does not cover the bulk of the matrix
+      TIN raw[NRB][NRB][4];
+      issue_kkt_loads<SH, TIN, 0, 1>(Q, A, lane, raw);
+      rhs_fetch();
+      issue_kkt_loads<SH, TIN, 1, NRB>(Q, A, lane, raw);
+      rhs_store();
+      convert_kkt_tiles<SH, TIN>(raw, a.rho, lane, C);
       // (the loads are still in flight here: the phase boundary is nominal, the wait falls into the
       // factorisation's first use of each tile)
       const long long t0 = wall_clock64();

@@ -651,6 +651,16 @@ int fccqp_phase_seconds(fccqp_solver *s, double out[8]) {
   return FCCQP_OK;
 }
 
+int fccqp_debug_phase_ticks(fccqp_solver *s, long long *out, long long count) {
+  if (!s || !out || count < 0) return FCCQP_ERR_INVALID_ARG;
+  DeviceGuard g(s->device);
+  const long long have = s->dphase ? 8ll * s->batch : 0;
+  if (!s->solved || count > have) return FCCQP_ERR_INVALID_ARG;
+  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, hipMemcpy(out, s->dphase, sizeof(long long) * (size_t)count, hipMemcpyDeviceToHost));
+  return FCCQP_OK;
+}
+
 int fccqp_debug_read_workspace(fccqp_solver *s, double *out, long long count, long long *available) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   DeviceGuard g(s->device);

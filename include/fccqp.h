@@ -207,6 +207,11 @@ int fccqp_last_kernel_ms(fccqp_solver *s, float *ms);
  * [4] ADMM iterations, [5] whole kernel per instance; [6],[7] reserved (0).  Profiling aid: the
  * first call enables the stamps for subsequent solves and returns zeros. */
 int fccqp_phase_seconds(fccqp_solver *s, double out[8]);
+/* The raw stamps behind fccqp_phase_seconds: out[p * batch + i], p = 0..7, 100 MHz ticks; slot 7 is the
+ * device clock at which instance i started, slot 5 its duration (so a launch can be laid out on a time
+ * line).  count <= 8 * batch; the stamps must have been enabled by a fccqp_phase_seconds call before the
+ * solve.  Debugging aid. */
+int fccqp_debug_phase_ticks(fccqp_solver *s, long long *out, long long count);
 /* Compulsory HBM bytes one solve of the whole batch moves:
  * 8 * batch * (n^2 + m*n + 4n + m + nc/3), plus the warm-start state when warm.  After an
  * fp32-storage solve the seven inputs count 4 bytes per element (z and the state stay 8). */

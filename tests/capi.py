@@ -71,6 +71,7 @@ def lib():
         L.fccqp_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.fccqp_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
         L.fccqp_phase_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.fccqp_debug_phase_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_longlong]
         _lib = L
     return _lib
 
@@ -165,6 +166,13 @@ class Solver:
         out = (C.c_double * 8)()
         self._ck(self.L.fccqp_phase_seconds(self.h, out), "phase_seconds")
         return list(out)
+
+    def phase_ticks(self):
+        """[8, batch] raw 100 MHz stamps (see include/fccqp.h)"""
+        import numpy as np
+        out = np.zeros(8 * self.batch, dtype=np.int64)
+        self._ck(self.L.fccqp_debug_phase_ticks(self.h, out.ctypes.data_as(C.POINTER(C.c_longlong)), out.size), "phase_ticks")
+        return out.reshape(8, self.batch)
 
     def algorithmic_bytes(self):
         b = C.c_longlong()

@@ -277,7 +277,7 @@ def test_low_rank_dense_cost_equality_only(oracle):
     assert np.max(np.abs(o.GetSolution().z - z[0])) <= 1e-8 * (1 + np.max(np.abs(z[0])))
 
 
-@pytest.mark.parametrize("dims", [(20, 14, 6, 10), (12, 5, 6, 3)], ids=["generic", "mini-fused"])
+@pytest.mark.parametrize("dims", [(20, 14, 6, 10), (12, 5, 6, 3), (12, 8, 6, 3)], ids=["generic", "mini-fused", "padded-fused"])
 def test_low_rank_dense_cost_with_admm(oracle, dims):
     """With contacts and bounds.  x0 (max_iter = 0: z = x0) is checked against K^-1 r from LAPACK.  The
     ADMM result is compared with the oracle on the instances where the oracle's OWN presolve was

@@ -558,7 +558,8 @@ __device__ __forceinline__ void tile_inverse_steps(double (&Y)[16], const double
 // Diagonal tile, column-per-lane (every 16-lane row of the wave holds a copy and does the same work):
 // in  T[i] = S[i][c], the symmetric 16 x 16 block;
 // out dmine = d_c, rmine = 1/d_c (pseudo-inverse rule), Y[i] = (L^-1)[i][c] for i > c (Y[c] = 1, Y[i < c] = 0).
-template <int NVALID>
+// (WITH_INVERSE = false: the last tile of a factorisation without right-hand sides -- nothing is solved with it)
+template <int NVALID, bool WITH_INVERSE = true>
 __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], double &dmine, double &rmine, const int c) {
   dmine = 1.0; rmine = 1.0;
   const double d0 = row_bcast<0>(T[0]);
@@ -576,7 +577,7 @@ __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], doubl
   }
   asm volatile("s_nop 1" : "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]), "+v"(T[8]));
   asm volatile("s_nop 1" : "+v"(T[9]), "+v"(T[10]), "+v"(T[11]), "+v"(T[12]), "+v"(T[13]), "+v"(T[14]), "+v"(T[15]));
-  tile_inverse_steps<0>(Y, T);
+  if constexpr (WITH_INVERSE) tile_inverse_steps<0>(Y, T);
   return bad;
 }
 
@@ -790,12 +791,15 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, lds_f64 *dvec, con
         T[2 * ip + 1] = t.y;
       }
       lds_fence();
-      FCCQP_FINE(0, bad |= tile_ldl<kValid>(T, Y, dmine, rmine, col));
+      constexpr bool kLast = (P + 1 == NW);
+      FCCQP_FINE(0, (bad |= tile_ldl<kValid, !kLast>(T, Y, dmine, rmine, col)));
       if (lane < 16) {
-        lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
+        if constexpr (!kLast) {
+          lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
 #pragma unroll
-        for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
-        Srcp[col] = rmine;
+          for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
+          Srcp[col] = rmine;
+        }
         // column 16 P + col of L (tile_ldl left T = -L), its d and 1/d
         if (col < kValid) {
           const int jcol = 16 * P + col, cb = SW::cbase(jcol);

@@ -233,7 +233,7 @@ struct Shape : Packed<N_VARS + N_EQ> {
   // nc == 0 with all-infinite bounds is the reference's equality-only case (fcc_qp.cpp:132-133: one
   // direct solve, no ADMM); such shapes go to the generic kernel, which keeps the direct presolve
   static_assert(nc > 0, "fused shapes have contacts");
-  // LDS carve (doubles): matrix | dvec[kNp] | vbuf[max(kNp, 64)]
+  // LDS carve (doubles): matrix | vbuf[max(kNp, 64)]
   static constexpr int kVbuf = (kNp > kWave) ? kNp : kWave;
   static constexpr int kLdsDoubles = kMat + kNp + kVbuf;
   static_assert(kLdsDoubles * 8 <= 160 * 1024 / 4, "four one-wave workgroups per CU");
@@ -522,10 +522,8 @@ __device__ __forceinline__ void tile_step_rows(double (&T)[16], const double neg
   }
 }
 template <int K>
-__device__ __forceinline__ void tile_steps(double (&T)[16], double d, double rinv, double &dmine, double &rmine,
-                                           const int c) {
+__device__ __forceinline__ void tile_steps(double (&T)[16], double d, double rinv, double &rmine, const int c) {
   if constexpr (K < 16) {
-    dmine = (c == K) ? d : dmine;
     rmine = (c == K) ? rinv : rmine;
     if constexpr (K < 15) {
       const double negm = (c > K) ? -pivot_quotient(T[K], d, rinv) : 0.0;
@@ -537,7 +535,7 @@ __device__ __forceinline__ void tile_steps(double (&T)[16], double d, double rin
       const double dn = row_bcast<K + 1>(T[K + 1]);
       const double rn = pivot_inverse(dn);
       tile_step_rows<K, K + 2>(T, negm);
-      tile_steps<K + 1>(T, dn, rn, dmine, rmine, c);
+      tile_steps<K + 1>(T, dn, rn, rmine, c);
     }
   }
 }
@@ -557,16 +555,20 @@ __device__ __forceinline__ void tile_inverse_steps(double (&Y)[16], const double
 }
 // Diagonal tile, column-per-lane (every 16-lane row of the wave holds a copy and does the same work):
 // in  T[i] = S[i][c], the symmetric 16 x 16 block;
-// out dmine = d_c, rmine = 1/d_c (pseudo-inverse rule), Y[i] = (L^-1)[i][c] for i > c (Y[c] = 1, Y[i < c] = 0).
+// out rmine = 1/d_c (pseudo-inverse rule: 0 for |d_c| <= DBL_MIN), Y[i] = (L^-1)[i][c] for i > c (Y[c] = 1,
+//     Y[i < c] = 0).  MAX_RCP: the largest reciprocal pivot still accepted (a definite matrix whose pivots
+//     must stay above 1 / MAX_RCP), or 0: then only a dropped or non-finite pivot (rmine 0 or NaN: d was
+//     zero, subnormal, infinite or NaN) is reported.  Padding rows are identity.
 // (WITH_INVERSE = false: the last tile of a factorisation without right-hand sides -- nothing is solved with it)
 template <int NVALID, bool WITH_INVERSE = true>
-__device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], double &dmine, double &rmine, const int c) {
-  dmine = 1.0; rmine = 1.0;
+__device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], double &rmine, const int c,
+                                         const double max_rcp = 0.0) {
+  rmine = 1.0;
   const double d0 = row_bcast<0>(T[0]);
-  tile_steps<0>(T, d0, pivot_inverse(d0), dmine, rmine, c);
-  // zero, infinite or NaN pivot (class mask: sNaN|qNaN|-inf|-0|+0|+inf), judged once: lane c holds d_c.
-  // (Padding rows are identity.)
-  const bool bad = __any((c < NVALID) && __builtin_amdgcn_class(dmine, 0x3 | 0x4 | 0x20 | 0x40 | 0x200));
+  tile_steps<0>(T, d0, pivot_inverse(d0), rmine, c);
+  // judged once per tile: lane c holds 1/d_c
+  const bool lane_bad = (max_rcp > 0.0) ? !(rmine > 0.0 && rmine < max_rcp) : __builtin_amdgcn_class(rmine, 0x3 | 0x20 | 0x40);
+  const bool bad = __any((c < NVALID) && lane_bad);
   // lane c now holds S_ic^(c) = l_ic d_c for i > c.  L^-1 by columns: y_i -= l_iK y_K, K < i, with l_iK fetched
   // from lane K (negated and scaled here, once)
   // (in place: T becomes -L)
@@ -688,7 +690,7 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
     lds_fence();
     double Ainv[4], nrv[4];
     {
-      double T[16], Y[16], dmine, rmine;
+      double T[16], Y[16], rmine;
       const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
 #pragma unroll
       for (int ip = 0; ip < 8; ++ip) {
@@ -697,7 +699,7 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
         T[2 * ip + 1] = t.y;
       }
       lds_fence();
-      FCCQP_FINE(0, bad |= tile_ldl<kValid>(T, Y, dmine, rmine, col));
+      FCCQP_FINE(0, bad |= tile_ldl<kValid>(T, Y, rmine, col));
       if (lane < 16) {
         lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
 #pragma unroll
@@ -760,10 +762,11 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
 
 // W = U^T D U by register tiles (the presolve, see fused_kernel), same scheme as tile_factor_forward without
 // right-hand sides; the factor is WRITTEN to LDS in the packed layout solve_lds reads (L = U^T below the
-// diagonal, 1/d in the diagonal slots, d in dvec).  Returns true if a pivot was zero or not finite.
+// diagonal, 1/d in the diagonal slots).  Returns true if a pivot was not above min_pivot (or not finite): W is
+// positive definite unless K is singular to working precision.
 // The exchange scratch sits behind the packed n x n image.
 template <class SH>
-__device__ __forceinline__ bool tile_factor_store(lds_f64 *M, lds_f64 *dvec, const int lane,
+__device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, const double min_pivot,
                                                   d4 (&C)[(SH::n + 15) / 16][(SH::n + 15) / 16], long long *fine = nullptr) {
   using SW = typename SH::Reduced;
   constexpr int n = SH::n, NW = (n + 15) / 16;
@@ -782,7 +785,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, lds_f64 *dvec, con
     lds_fence();
     double Ainv[4], rv[4];
     {
-      double T[16], Y[16], dmine, rmine;
+      double T[16], Y[16], rmine;
       const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
 #pragma unroll
       for (int ip = 0; ip < 8; ++ip) {
@@ -792,7 +795,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, lds_f64 *dvec, con
       }
       lds_fence();
       constexpr bool kLast = (P + 1 == NW);
-      FCCQP_FINE(0, (bad |= tile_ldl<kValid, !kLast>(T, Y, dmine, rmine, col)));
+      FCCQP_FINE(0, (bad |= tile_ldl<kValid, !kLast>(T, Y, rmine, col, 1.0 / min_pivot)));
       if (lane < 16) {
         if constexpr (!kLast) {
           lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
@@ -803,7 +806,6 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, lds_f64 *dvec, con
         // column 16 P + col of L (tile_ldl left T = -L), its d and 1/d
         if (col < kValid) {
           const int jcol = 16 * P + col, cb = SW::cbase(jcol);
-          dvec[jcol] = dmine;
           M[cb + jcol] = rmine;
 #pragma unroll
           for (int i = 1; i < kValid; ++i)
@@ -1015,8 +1017,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   constexpr int n = SH::n, m = SH::m, nc = SH::nc, s0 = SH::s, N = SH::N;
   __shared__ __attribute__((aligned(16))) double lds_raw[SH::kLdsDoubles];
   lds_f64 *const M = (lds_f64 *)lds_raw;
-  lds_f64 *const dvec = M + SH::kMat;
-  lds_f64 *const vbuf = dvec + SH::kNp;
+  lds_f64 *const vbuf = M + SH::kMat + SH::kNp;
 
   const int lane = threadIdx.x;
   const int inst = blockIdx.x;
@@ -1154,12 +1155,10 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       // W arrives as register tiles from the Gram product; its factor goes to LDS (over the rho G image:
       // row `var` of rho G is in registers by now) for the two triangular sweeps
       const long long tw = wall_clock64();
-      bool wbad = tile_factor_store<SH>(M, dvec, lane, Wt, fine_w);
+      const bool wbad = tile_factor_store<SH>(M, lane, kPresolveMinPivot, Wt, fine_w);
 #ifdef FCCQP_FINE_STAMPS
       fine_w[1] = wall_clock64() - tw;       // the whole factorisation of W
 #endif
-      const double dw = dvec[vi];
-      wbad = wbad || __any(!(dw > kPresolveMinPivot));
       ticks += wall_clock64() - tw;
       if (wbad) {
         flags |= kFlagPresolveNumerical;
@@ -1235,6 +1234,9 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       lds_fence();
     };
     if (max_iter > 0) exchange_w();
+    // the loop header on an instruction-cache line boundary: the time per iteration moved by 5 % with
+    // nothing but the placement of the (otherwise identical) loop in the code
+    asm volatile(".p2align 8");
 #pragma nounroll
     for (int iter = 0; iter < max_iter; ++iter) {
       double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0};

@@ -155,7 +155,7 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s) && fccqp::fused_pointers_ok(a);
   if (s->kernel_request == FCCQP_KERNEL_FUSED && !can_fuse)
     return fail(s, FCCQP_ERR_UNSUPPORTED,
-                "no fused kernel for this shape, or Q / A_eq not 16-byte aligned");
+                "no fused kernel for this shape");
   // the handle's state (warm-start vectors, fallback list, counters, workspace) is shared by every
   // solve: a solve enqueued on another stream than the previous one waits for it on the device
   if (s->solved && stream != s->last_stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev1, 0));

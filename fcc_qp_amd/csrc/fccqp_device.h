@@ -80,7 +80,7 @@ long long cod_workspace_doubles_host(int n, int m);
 
 // ---- fused shape-specialised kernels (fccqp_fused.hip) ---------------------------------------
 bool fused_supported(int n, int m, int nc, int s);
-bool fused_pointers_ok(const KernelArgs &a);  // 16-byte alignment of Q and A_eq
+bool fused_pointers_ok(const KernelArgs &a);  // (always true since the tile loader: natural alignment suffices)
 hipError_t launch_fused(const KernelArgs &a, hipStream_t stream, bool qa_f32);
 
 }  // namespace fccqp

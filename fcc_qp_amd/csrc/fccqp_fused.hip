@@ -42,7 +42,6 @@ hipError_t launch_by_shape(const KernelArgs &a, hipStream_t stream) {
   if (matches<Padded>(a.n, a.m, a.nc, a.s)) return launch<Padded>(a, stream);
   return hipErrorNotSupported;
 }
-bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 }  // namespace
 
 #ifdef FCCQP_FUSED_STORAGE_F32
@@ -54,10 +53,10 @@ bool fused_supported(int n, int m, int nc, int s) {
   return matches<Walking>(n, m, nc, s) || matches<Mini>(n, m, nc, s) || matches<Padded>(n, m, nc, s);
 }
 
-bool fused_pointers_ok(const KernelArgs &a) {
-  // Q and A_eq are fetched two elements at a time (16 bytes as double, 8 as float; hipMalloc'd
-  // and torch buffers are 256-byte aligned either way)
-  return aligned16(a.Q) && aligned16(a.A);
+bool fused_pointers_ok(const KernelArgs &) {
+  // Q and A_eq are read one element per lane (issue_kkt_loads): natural alignment is all that is needed.
+  // (Rounds 1-2c fetched them 16 bytes at a time and sent misaligned arrays to the generic kernel.)
+  return true;
 }
 
 hipError_t launch_fused(const KernelArgs &a, hipStream_t stream, bool qa_f32) {

@@ -155,8 +155,8 @@ int fccqp_host_unregister(void *ptr);
 /* Device-pointer form: the seven arrays are already resident in HBM on the solver's device
  * (instance-major, friction stride nc/3).  Enqueues on `stream` and returns without waiting.
  * `stream` is a hipStream_t: NULL is HIP's default (null) stream, as everywhere in HIP;
- * FCCQP_STREAM_OWN selects the solver's private non-blocking stream.  The fused kernel fetches
- * Q and A_eq 16 bytes at a time: if either is not 16-byte aligned the generic kernel is used. */
+ * FCCQP_STREAM_OWN selects the solver's private non-blocking stream.  The arrays need only the
+ * natural alignment of their element type (the kernels read Q and A_eq one element per lane). */
 #define FCCQP_STREAM_OWN ((void *)(intptr_t)-1)
 int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, const double *dA_eq,
                        const double *db_eq, const double *dfriction, const double *dlb,

@@ -127,6 +127,30 @@ def test_torch_tensors_resident_in_hbm_give_the_same_bits():
     assert ptrs["z"] != 0 and ptrs["n_iter"] != 0
 
 
+def test_device_arrays_need_only_natural_alignment():
+    """Q and A_eq views that start 8 bytes (fp64) / 4 bytes (fp32) into an allocation: the fused kernel reads
+    them one element per lane, so they take the same kernel and give the same bits as aligned copies."""
+    import torch
+    import fcc_qp_amd as F
+    nb = 32
+    B = P.workload("W-mix", nb, P.WALKING)
+    bs = F.FCCQPBatch(60, 38, 12, 38, nb); bs.set_options(harness_options(F))
+    for dtype in (torch.float64, torch.float32):
+        tens = [torch.from_numpy(a).cuda().to(dtype) for a in B.arrays()]
+        F.solve_tensors(bs, *tens); torch.cuda.synchronize()
+        ref = bs.GetSolution()
+        shifted = []
+        for t in tens:
+            buf = torch.empty(t.numel() + 1, dtype=dtype, device="cuda")
+            v = buf[1:].view(t.shape)
+            v.copy_(t)
+            assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+            shifted.append(v)
+        F.solve_tensors(bs, *shifted); torch.cuda.synchronize()
+        got = bs.GetSolution()
+        assert np.array_equal(got.z, ref.z) and np.array_equal(got.n_iter, ref.n_iter)
+
+
 def test_harness_reproduces_reference_loop_and_series(oracle, tmp_path):
     """fcc_qp_amd.harness: the reference's load -> warm-started loop -> eight series
     (/root/reference/fcc_qp_test.py:22-32,44-69,72-89) from a log file in the reference's format."""

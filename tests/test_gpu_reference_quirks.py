@@ -229,6 +229,35 @@ def test_rank_deficient_equality_rows(oracle, kernel):
     assert np.max(np.abs(r)) <= 1e-6 * (1 + np.max(np.abs(B.b_eq)))
 
 
+def test_duplicate_rows_inside_a_tile_equal_the_reduced_problem(oracle):
+    """Two adjacent, identical equality rows in the middle of A_eq (KKT rows 70 and 71: one 16 x 16 diagonal
+    tile of the fused kernel).  The reference's restatement is not well defined here (above), but the
+    problem is: the copy adds nothing, so the solution is that of the QP without it.  The fused kernel's
+    multipliers are exact quotients (fccqp_fused_impl.h: pivot_quotient), so the copy eliminates to an
+    exactly zero column and pivot, which the pseudo-inverse rule drops -- compared with the oracle on
+    the reduced shape FCCQP(60, 37, 12, 38)."""
+    base = P.workload("W-mix", 6, P.WALKING)
+    qps, reduced = [], []
+    for i in range(6):
+        q = {k: np.array(v, copy=True) for k, v in base.instance(i).items()}
+        q["A_eq"][11] = q["A_eq"][10]; q["b_eq"][11] = q["b_eq"][10]
+        qps.append(q)
+        r = dict(q); r["A_eq"] = np.delete(q["A_eq"], 11, axis=0); r["b_eq"] = np.delete(q["b_eq"], 11)
+        reduced.append(r)
+    B = P.stack(qps)
+    z, it, d, _ = gpu_solve(P.WALKING.ctor_args, P.HARNESS_OPTIONS, B, CAPI.KERNEL_FUSED)
+    assert np.all(np.isfinite(z))
+    for i, r in enumerate(reduced):
+        o = oracle.OracleFCCQP(60, 37, 12, 38)
+        op = oracle.FCCQPOptions(); op.__dict__.update(P.HARNESS_OPTIONS); o.set_options(op)
+        o.Solve(**r)
+        zr = o.GetSolution().z
+        assert np.max(np.abs(z[i] - zr)) <= Z_TOL * (1 + np.max(np.abs(zr))), i
+        assert d[i].flags & CAPI.FLAG_ADMM_NUMERICAL, i      # the dropped pivot is reported
+    res = np.einsum("bij,bj->bi", B.A_eq, z) - B.b_eq
+    assert np.max(np.abs(res)) <= 1e-6 * (1 + np.max(np.abs(B.b_eq)))
+
+
 # ---- semi-definite costs: the reference's COD branch without the COD ------------------------------------
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_w_psd_matches_oracle(oracle, kernel):

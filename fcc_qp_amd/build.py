@@ -53,6 +53,7 @@ def build_lib(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip",
                                             "fccqp_fused_f32.hip")]
     deps = srcs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
+                          os.path.join(CSRC, "fused_shapes.def"),
                           os.path.join(CSRC, "fccqp_cod_impl.h"),
                           os.path.join(ROOT, "include", "fccqp.h")]
     if force or _newer(LIB, deps):

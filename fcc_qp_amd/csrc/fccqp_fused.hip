@@ -1,19 +1,13 @@
-// fccqp_fused.hip -- instantiations and launcher of the shape-specialised kernel
-// (fccqp_fused_impl.h).  Shapes compiled in:
-//   walking  FCCQP(60, 38, 12, 38)   reference harness shape, /root/reference/fcc_qp_test.py:77
-//   mini     FCCQP(12, 5, 6, 3)      small shape that exercises the same template in the tests (N = 17: one
-//                                    bordered row, like the walking shape's two)
-//   padded   FCCQP(12, 8, 6, 3)      N = 20: four rows past the last full tile, more than the border takes --
-//                                    the identity-padded last tile row of the same template
+// fccqp_fused.hip -- instantiations and launcher of the shape-specialised kernel (fccqp_fused_impl.h) for the
+// shapes listed in fused_shapes.def (an X-macro list: one FCCQP_FUSED_SHAPE(n, m, nc, s) per line).
 // Compiled twice: as is (Q / A_eq stored as double) and through fccqp_fused_f32.hip (as float).
 #include "fccqp_fused_impl.h"
 
 namespace fccqp {
-using Walking = fused::Shape<60, 38, 12, 38>;
-using Mini = fused::Shape<12, 5, 6, 3>;
-using Padded = fused::Shape<12, 8, 6, 3>;
-static_assert(Walking::kBorder == 2 && Mini::kBorder == 1 && Padded::kBorder == 0, "the three tile-edge cases");
-
+// the three tile-edge cases of the template are always among the compiled shapes (tests)
+static_assert(fused::Shape<60, 38, 12, 38>::kBorder == 2 && fused::Shape<12, 5, 6, 3>::kBorder == 1 &&
+                  fused::Shape<12, 8, 6, 3>::kBorder == 0,
+              "two bordered rows, one, identity padding");
 
 namespace {
 // One storage type per translation unit.  With the float and double instantiations in the same
@@ -37,9 +31,10 @@ hipError_t launch(const KernelArgs &a, hipStream_t stream) {
 }
 hipError_t launch_by_shape(const KernelArgs &a, hipStream_t stream) {
   if (a.batch <= 0) return hipSuccess;
-  if (matches<Walking>(a.n, a.m, a.nc, a.s)) return launch<Walking>(a, stream);
-  if (matches<Mini>(a.n, a.m, a.nc, a.s)) return launch<Mini>(a, stream);
-  if (matches<Padded>(a.n, a.m, a.nc, a.s)) return launch<Padded>(a, stream);
+#define FCCQP_FUSED_SHAPE(N_, M_, NC_, S_) \
+  if (matches<fused::Shape<N_, M_, NC_, S_>>(a.n, a.m, a.nc, a.s)) return launch<fused::Shape<N_, M_, NC_, S_>>(a, stream);
+#include "fused_shapes.def"
+#undef FCCQP_FUSED_SHAPE
   return hipErrorNotSupported;
 }
 }  // namespace
@@ -50,7 +45,11 @@ hipError_t launch_fused_f32(const KernelArgs &a, hipStream_t stream) { return la
 hipError_t launch_fused_f32(const KernelArgs &a, hipStream_t stream);   // fccqp_fused_f32.hip
 
 bool fused_supported(int n, int m, int nc, int s) {
-  return matches<Walking>(n, m, nc, s) || matches<Mini>(n, m, nc, s) || matches<Padded>(n, m, nc, s);
+#define FCCQP_FUSED_SHAPE(N_, M_, NC_, S_) \
+  if (matches<fused::Shape<N_, M_, NC_, S_>>(n, m, nc, s)) return true;
+#include "fused_shapes.def"
+#undef FCCQP_FUSED_SHAPE
+  return false;
 }
 
 bool fused_pointers_ok(const KernelArgs &) {

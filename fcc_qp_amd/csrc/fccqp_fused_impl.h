@@ -211,34 +211,28 @@ struct Packed {
   // cbase(j + 1) - cbase(j): lets loops walk the columns with one scalar add
   static constexpr int cstep(int j) { return N - j - 1 + (((j & 1) == (N & 1)) ? 1 : 0); }
   static constexpr int kPacked = (cstart(N) + 1) & ~1;
-  // The image doubles as the exchange scratch of tile_factor_forward (kScratch doubles at its start) and
-  // keeps the reciprocal pivots of all (padded) rows behind both the scratch and the later rho G image.
+  // exchange scratch of the diagonal tiles (tile_factor_forward, tile_factor_store): the tile, its inverse,
+  // 16 reciprocal pivots (+ padding)
   static constexpr int kScratch = 544;
   static constexpr int kRowsPadded = 16 * ((N + 15) / 16);
-  // (small shapes: 2 kScratch leaves room for the presolve's packed n x n factor in front of its scratch)
-  static constexpr int kMat = (kPacked > 2 * kScratch) ? kPacked : 2 * kScratch;
   static constexpr int kNp = (N + 1) & ~1;
 };
 
 template <int N_VARS, int N_EQ, int NC, int LC_START>
 struct Shape : Packed<N_VARS + N_EQ> {
   using KKT = Packed<N_VARS + N_EQ>;
-  using KKT::N; using KKT::kMat; using KKT::kNp;
-  // the n x n matrix W = I - rho G of the presolve (see fused_kernel) reuses the front of the image
+  using KKT::N; using KKT::kNp;
+  // the packed n x n factor of W = I - rho G for the presolve's two sweeps (see fused_kernel)
   using Reduced = Packed<N_VARS>;
   static constexpr int n = N_VARS, m = N_EQ, nc = NC, s = LC_START;
   static_assert(n >= 1 && n < kWave, "one lane per variable plus one lane for the rhs column");
-  static_assert(N <= 2 * kWave, "two KKT rows per lane");
+  static_assert(m >= 0 && m <= kWave, "one lane per equality row when the right-hand side is staged");
   static_assert(nc % 3 == 0 && s + nc <= n, "fcc_qp.cpp:32-33");
   // nc == 0 with all-infinite bounds is the reference's equality-only case (fcc_qp.cpp:132-133: one
   // direct solve, no ADMM); such shapes go to the generic kernel, which keeps the direct presolve
   static_assert(nc > 0, "fused shapes have contacts");
-  // LDS carve (doubles): matrix | vbuf[max(kNp, 64)]
-  static constexpr int kVbuf = (kNp > kWave) ? kNp : kWave;
-  static constexpr int kLdsDoubles = kMat + kNp + kVbuf;
-  static_assert(kLdsDoubles * 8 <= 160 * 1024 / 4, "four one-wave workgroups per CU");
-  static_assert(n * n + KKT::kRowsPadded <= kMat, "rho G (n x n, row-major) and 1/d fit over the dead factor");
-  // where tile_factor_forward leaves 1/d_row for gram_output
+  // where tile_factor_forward leaves 1/d_row for gram_output: behind the exchange scratch and behind the rho G
+  // image (n x n, row-major) that gram_output writes
   static constexpr int kRcpOffset = (n * n > KKT::kScratch) ? n * n : KKT::kScratch;
   // Bordering.  16 x 16 tiles waste most of a last row block that holds only N % 16 rows (walking shape:
   // 2 of 16, and a fifth of all MFMAs touch it).  When those last rows lie in the zero block and the
@@ -253,8 +247,17 @@ struct Shape : Packed<N_VARS + N_EQ> {
   // LDS staging of the border columns (kBorder x kTileRows, behind the reciprocal pivots) and, later, of
   // the Gram columns n .. n + kBorder (rows 0 .. n + kBorder)
   static constexpr int kBorderOffset = kRcpOffset + KKT::kRowsPadded;
-  static_assert(kBorderOffset + kBorder * kTileRows <= kMat && kBorderOffset + (n + kBorder + 1) * (kBorder + 1) <= kMat,
-                "border staging fits behind the image");
+  static constexpr int kBorderDoubles =
+      (kBorder * kTileRows > (n + kBorder + 1) * (kBorder + 1)) ? kBorder * kTileRows : (n + kBorder + 1) * (kBorder + 1);
+  // LDS carve (doubles): work area M[kMat] | vbuf[max(kNp, 64)].  M holds, in turn: the exchange scratch,
+  // 1/d and the border staging during the factorisation; the rho G image; the packed factor of W and its
+  // exchange scratch.  (The matrix itself never is in LDS: it lives in registers.)
+  static constexpr int kMatFactor = kBorderOffset + kBorderDoubles;
+  static constexpr int kMatPresolve = ((Reduced::kPacked + 1) & ~1) + KKT::kScratch;
+  static constexpr int kMat = (((kMatFactor > kMatPresolve) ? kMatFactor : kMatPresolve) + 1) & ~1;
+  static constexpr int kVbuf = (kNp > kWave) ? kNp : kWave;
+  static constexpr int kLdsDoubles = kMat + kVbuf;
+  static_assert(kLdsDoubles * 8 <= 160 * 1024 / 4, "four one-wave workgroups per CU");
   // Lane <-> variable map of the ADMM loop.  Contact c owns lanes 4c, 4c+1, 4c+2 (x, y, z): a lane
   // gets the three components of its contact force with quad_perm DPP moves instead of an LDS round
   // trip per iteration.  The other variables fill the fourth lane of those quads, then the lanes past
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   constexpr int n = SH::n, m = SH::m, nc = SH::nc, s0 = SH::s, N = SH::N;
   __shared__ __attribute__((aligned(16))) double lds_raw[SH::kLdsDoubles];
   lds_f64 *const M = (lds_f64 *)lds_raw;
-  lds_f64 *const vbuf = M + SH::kMat + SH::kNp;
+  lds_f64 *const vbuf = M + SH::kMat;
 
   const int lane = threadIdx.x;
   const int inst = blockIdx.x;
@@ -1078,7 +1081,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 #pragma unroll
       for (int bb = 0; bb < SH::kBorder; ++bb) {
         lds_f64 *bp_ = M + SH::kBorderOffset + bb * SH::kTileRows;
-        bp_[lane] = isnat ? (double)rhs_border[bb] : 0.0;
+        if (lane < SH::kTileRows) bp_[lane] = isnat ? (double)rhs_border[bb] : 0.0;
         if (kWave + lane < SH::kTileRows) bp_[kWave + lane] = 0.0;
       }
     }

@@ -17,7 +17,7 @@
 //     needs sits in a lane of the same row.
 //   * 512 registers per lane (256 VGPR + 256 AGPR, MFMA reads and writes both) hold the whole upper
 //     triangle of the 98 x 98 KKT matrix as 28 accumulator tiles plus the right-hand-side tiles; LDS
-//     (39 KB per QP) holds the assembled image once, then exchange scratch, rho G and the presolve factor.
+//     (32 KB per QP) holds exchange scratch, rho G and the presolve factor -- never the matrix.
 //
 // Phases, N = n + m (walking shape: n = 60, m = 38, N = 98):
 //   P0  assemble the lower triangle of K_rho = [[Q + rho I, A^T],[A, 0]] in LDS, ONCE (coalesced

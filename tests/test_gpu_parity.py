@@ -446,3 +446,23 @@ def test_fused_and_generic_kernels_agree_on_a_random_population():
     assert err.max() <= Z_TOL_TIGHT, err.max()
     assert np.max(np.abs(zs[0][1] - zs[1][1])) <= 1
     assert np.array_equal(zs[0][0][:128], zs[0][0][128:256])     # tiled copies: bit-identical
+
+
+def test_phase_stamps_cover_the_launch():
+    """fccqp_phase_seconds / fccqp_debug_phase_ticks (fused kernel): every instance stamped, the phases sum to
+    the instance total, the instances fit inside the launch timed by hipEvents."""
+    nb = 2048
+    B = P.workload("W-sat", nb, P.WALKING, distinct=64)
+    s = CAPI.Solver(*P.WALKING.ctor_args, batch=nb); s.set_options(**P.HARNESS_OPTIONS); s.set_kernel(CAPI.KERNEL_FUSED)
+    assert s.phase_seconds() == [0.0] * 8                 # first call only enables the stamps
+    s.solve_ok(*B.arrays()); s.solve_ok(*B.arrays())
+    ms = s.kernel_ms()
+    ph = s.phase_seconds()
+    t = s.phase_ticks()
+    assert t.shape == (8, nb) and np.all(t[5] > 0)
+    total_us = t[5] * 1e-2
+    parts_us = (t[0] + t[1] + t[2] + t[3] + t[4]) * 1e-2       # W's factorisation is in both [1] and [2]
+    assert np.all(parts_us <= 1.25 * total_us) and np.all(parts_us >= 0.8 * total_us)
+    span_us = (t[7] + t[5]).max() * 1e-2 - t[7].min() * 1e-2
+    assert 0.5 * ms * 1e3 <= span_us <= 1.05 * ms * 1e3
+    assert abs(ph[5] - total_us.mean() * 1e-6) <= 1e-9

@@ -15,13 +15,15 @@
 //     lets an FMA read lane k of its 16-lane row.  Every sequential piece of the path (diagonal-tile
 //     elimination, tile inverse, the mat-vec of an ADMM iteration) is laid out so that the operand it
 //     needs sits in a lane of the same row.
-//   * 512 registers per lane (256 VGPR + 256 AGPR, MFMA reads and writes both) hold the whole upper
-//     triangle of the 98 x 98 KKT matrix as 28 accumulator tiles plus the right-hand-side tiles; LDS
-//     (32 KB per QP) holds exchange scratch, rho G and the presolve factor -- never the matrix.
+//   * 512 registers per lane (256 VGPR + 256 AGPR, MFMA reads and writes both) hold the upper triangle
+//     of the leading 96 x 96 block of the KKT matrix as 21 accumulator tiles plus the right-hand-side
+//     tiles; LDS (32 KB per QP) holds exchange scratch, rho G and the presolve factor -- never the matrix.
 //
 // Phases, N = n + m (walking shape: n = 60, m = 38, N = 98):
-//   P0  assemble the lower triangle of K_rho = [[Q + rho I, A^T],[A, 0]] in LDS, ONCE (coalesced
-//       16-byte reads of Q and A_eq; fcc_qp.cpp:146-150,62-64).
+//   P0  K_rho = [[Q + rho I, A^T],[A, 0]] (fcc_qp.cpp:146-150,62-64) from HBM straight into accumulator-layout
+//       tiles, ONCE (issue_kkt_loads: only the lower triangle of Q is read; the loads of row panel 0
+//       first, so that its diagonal tile is factorised while the rest is in flight).  The last N % 16
+//       rows, when they are few, are not tiled but bordered (Shape::kBorder).
 //   P1  factorise K_rho (fcc_qp.cpp:68) with the forward solve of [e_0 .. e_{n-1} | -b; b_eq] fused in
 //       (tile_factor_forward): unpivoted, natural order, right-looking by 16 x 16 register tiles in
 //       the form U^T D U, in which every trailing update contracts over the ROWS of the panel's
@@ -1038,11 +1040,11 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   double *mulc_s = a.mu_lc + (size_t)inst * nc;
 
   // ---- vectors.  Two lane <-> variable maps: the natural one (lane i <-> variable i, i < n; lane r <->
-  // equality row r) for the assembly, the right-hand side and the presolve solve, and
+  // equality row r) for the right-hand side and the presolve solve, and
   // Shape::lane_variable (each contact in a quad of lanes) for rho G, the ADMM loop and the epilogue ----
   // The small vectors (b, b_eq, lb, ub, mu, warm-start state) are fetched from global memory at
-  // the point of use instead of being held in registers across the phases: P3 needs nearly the
-  // whole register file, and anything live across it is spilled to scratch and reloaded inside
+  // the point of use instead of being held in registers across the phases: the factorisation needs
+  // nearly the whole register file, and anything live across it is spilled to scratch and reloaded inside
   // the ADMM loop.  `fresh()` hides the pointer from CSE so the loads really are redone.
   auto fresh = [](const double *p) { asm volatile("" : "+s"(p)); return p; };
   const bool isnat = lane < n;
@@ -1090,11 +1092,11 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 
   int n_iter = 0;
   double x_res_norm = 0.0, lc_res_norm = 0.0;
-  // phase stamps (100 MHz): 0 assemble, 1 factor, 2 presolve (W), 3 P3, 4 P4, 5 total
+  // phase stamps (100 MHz): 0 load issue, 1 factorisations, 2 presolve (W), 3 Gram product, 4 ADMM loop, 5 total
   long long ph_asm = 0, ph_solve = 0, ph_p3 = 0, ph_p4 = 0;
   const long long t_begin = wall_clock64();
 
-  // ---- P0 + P1: K_rho = K + rho [I 0; 0 0], assembled and factorised ONCE (fcc_qp.cpp:62-68) ------
+  // ---- P0 + P1: K_rho = K + rho [I 0; 0 0], loaded and factorised ONCE (fcc_qp.cpp:62-68) ------------
   // The reference factorises twice on a cold start: K for the presolve x0 = (K^-1 [-b; b_eq]).head(n)
   // (fcc_qp.cpp:159-178) and K_rho for the iterations.  Here x0 comes out of the K_rho factorisation
   // (see "presolve" below), so Q and A_eq are read from HBM exactly once and the second N^3/3 is
@@ -1144,7 +1146,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     // W = I - rho G is symmetric, with eigenvalue 1 on range(A_eq^T) and lambda / (lambda + rho) for
     // every eigenvalue lambda of the reduced Hessian Z^T Q Z: positive definite exactly when K is
     // non-singular, and far better conditioned than K (cond <= 1 + rho / lambda_min).  It is
-    // factorised by the same panel LDL^T (n x n: n^3/3 instead of N^3/3 flops, no second assembly,
+    // factorised by the same register tiles (n x n: n^3/3 instead of N^3/3 flops, no second assembly,
     // no second pass over Q / A_eq in HBM).  Against the exact K^-1 r this x0 is accurate to ~1e-14
     // relative on the walking workloads at the harness rho, ~1e-11 at rho = 0.1 (the direct
     // unpivoted LDL^T of K: ~1e-13; tools/woodbury_presolve.py), and it exists for semi-definite

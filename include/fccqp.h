@@ -202,10 +202,12 @@ int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x,
 /* Milliseconds the last solve's kernel(s) took on the device (hipEvent pair on the launch
  * stream); waits for the solve. */
 int fccqp_last_kernel_ms(fccqp_solver *s, float *ms);
-/* Mean device time (seconds) the instances of the last solve spent per phase, fused kernel only:
- * out[0] KKT assembly, [1] factorisations, [2] presolve triangular solve, [3] P3 (G and x_c),
- * [4] ADMM iterations, [5] whole kernel per instance; [6],[7] reserved (0).  Profiling aid: the
- * first call enables the stamps for subsequent solves and returns zeros. */
+/* Mean device time (seconds) the instances of the last solve spent per phase (fused kernel; the generic
+ * kernel fills the slots it has): out[0] issue of the matrix loads (assembly on the generic kernel),
+ * [1] factorisations (K_rho with the fused forward solve, and W), [2] presolve (W's factorisation and the
+ * two sweeps), [3] Gram product: rho G, x_c, W, [4] ADMM iterations, [5] whole kernel per instance;
+ * [6],[7] reserved.  Profiling aid: the first call enables the stamps for subsequent solves and returns
+ * zeros. */
 int fccqp_phase_seconds(fccqp_solver *s, double out[8]);
 /* The raw stamps behind fccqp_phase_seconds: out[p * batch + i], p = 0..7, 100 MHz ticks; slot 7 is the
  * device clock at which instance i started, slot 5 its duration (so a launch can be laid out on a time

@@ -5,7 +5,7 @@
 
 namespace fccqp {
 // the three tile-edge cases of the template are always among the compiled shapes (tests)
-static_assert(fused::Shape<60, 38, 12, 38>::kBorder == 2 && fused::Shape<12, 5, 6, 3>::kBorder == 1 &&
+static_assert(fused::Shape<60, 38, 12, 38>::kBorder == 2 && fused::Shape<12, 5, 6, 3>::kBorder == 1 && fused::Shape<12, 7, 6, 3>::kBorder == 3 &&
                   fused::Shape<12, 8, 6, 3>::kBorder == 0,
               "two bordered rows, one, identity padding");
 

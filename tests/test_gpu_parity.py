@@ -78,6 +78,7 @@ def _random_qp(rng, n, m, nc, s, finite_bounds=True):
 
 
 @pytest.mark.parametrize("dims", [(3, 0, 3, 0), (7, 2, 3, 4), (12, 5, 6, 3),   # fused: one bordered row (N = 17)
+                                  (12, 7, 6, 3),        # fused: three bordered rows (N = 19)
                                   (12, 8, 6, 3),        # fused: identity-padded last tile row (N = 20), no border
                                   (32, 14, 6, 20),      # fused: n a multiple of 16, padded (N = 46)
                                   (32, 18, 6, 20),      # fused: n a multiple of 16, two bordered rows (N = 50)

@@ -14,7 +14,8 @@ _spec = importlib.util.spec_from_file_location(
 E = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(E)
 
-SHAPES = {"walking": (60, 38), "mini": (12, 5), "padded": (12, 8)}
+SHAPES = {"walking": (60, 38), "mini": (12, 5), "border3": (12, 7), "padded": (12, 8), "n32-border": (32, 18),
+          "n32-padded": (32, 14)}
 
 
 def _qp(rng, n, m):
@@ -25,7 +26,7 @@ def _qp(rng, n, m):
 @pytest.mark.parametrize("name", SHAPES)
 def test_border_rule(name):
     n, m = SHAPES[name]
-    assert E.border_rows(n, m) == {"walking": 2, "mini": 1, "padded": 0}[name]
+    assert E.border_rows(n, m) == {"walking": 2, "mini": 1, "border3": 3, "padded": 0, "n32-border": 2, "n32-padded": 0}[name]
 
 
 @pytest.mark.parametrize("name", SHAPES)

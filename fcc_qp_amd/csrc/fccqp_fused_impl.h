@@ -669,7 +669,10 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * I + grp + 4 * r, c = 16 * cb + col;
-      double v = (row == c && c < n) ? 1.0 : 0.0;
+      // (I and cb are constants once the callers' loops are unrolled: a tile off the diagonal that is not in
+      // the dense column block is the literal zero tile -- no registers, srcC = 0 in its first MFMA)
+      double v = 0.0;
+      if (I == cb) v = (row == c && c < n) ? 1.0 : 0.0;
       if (cb == cbd) {
         v = (c == n) ? ((row < N) ? vbuf[row < N ? row : 0] : 0.0) : v;
         if constexpr (SH::kBorder > 0) {   // columns n+1 .. n+kBorder: the border columns of K_rho (staged by the caller)

@@ -38,6 +38,15 @@ struct fccqp_solver {
   double *wb = nullptr, *wbeq = nullptr, *wmu = nullptr, *wlb = nullptr, *wub = nullptr;  // widened vectors
   double *dQ = nullptr, *db = nullptr, *dA = nullptr, *dbeq = nullptr, *dmu = nullptr,
          *dlb = nullptr, *dub = nullptr;
+  // The seven staged inputs are carved out of ONE device block, and (small batches) mirrored by one
+  // page-locked host block of the same layout: a host-pointer solve of a few instances is one
+  // memcpy-into-pinned + one H2D copy instead of seven staged copies from pageable memory (~10 us each:
+  // more than the kernel takes for the reference's one-instance-at-a-time use).
+  char *din_block = nullptr, *hin_block = nullptr;
+  size_t in_off[7] = {0, 0, 0, 0, 0, 0, 0}, in_bytes = 0;
+  // Likewise the per-instance results (z, metrics, ticks, n_iter, flags): one device block, one D2H copy.
+  char *dres_block = nullptr, *hres_block = nullptr;
+  size_t res_off[5] = {0, 0, 0, 0, 0}, res_bytes = 0;
   // state / outputs
   double *dx = nullptr, *dmux = nullptr, *dmulc = nullptr, *dmetrics = nullptr, *dwork = nullptr;
   int *dniter = nullptr, *dflags = nullptr;
@@ -106,16 +115,27 @@ hipError_t dmalloc(T **p, size_t count) {
 
 size_t n_mu(const fccqp_solver *s) { return (size_t)(s->nc / 3); }
 
+// host-pointer solves of at most this many bytes go through the page-locked mirror blocks
+constexpr size_t kPinnedMirrorBytes = 1u << 20;
+size_t align256(size_t v) { return (v + 255u) & ~size_t(255); }
+
 int ensure_staging(fccqp_solver *s) {
-  if (s->dQ) return FCCQP_OK;
+  if (s->din_block) return FCCQP_OK;
   const size_t B = (size_t)s->batch, n = (size_t)s->n, m = (size_t)s->m;
-  HIP_TRY(s, dmalloc(&s->dQ, B * n * n));
-  HIP_TRY(s, dmalloc(&s->db, B * n));
-  HIP_TRY(s, dmalloc(&s->dA, B * m * n));
-  HIP_TRY(s, dmalloc(&s->dbeq, B * m));
-  HIP_TRY(s, dmalloc(&s->dmu, B * n_mu(s)));
-  HIP_TRY(s, dmalloc(&s->dlb, B * n));
-  HIP_TRY(s, dmalloc(&s->dub, B * n));
+  const size_t counts[7] = {B * n * n, B * n, B * m * n, B * m, B * n_mu(s), B * n, B * n};
+  size_t off = 0;
+  for (int i = 0; i < 7; ++i) {
+    s->in_off[i] = off;
+    off += align256(sizeof(double) * (counts[i] ? counts[i] : 1));
+  }
+  s->in_bytes = off;
+  HIP_TRY(s, dmalloc(&s->din_block, off));
+  double **dst[7] = {&s->dQ, &s->db, &s->dA, &s->dbeq, &s->dmu, &s->dlb, &s->dub};
+  for (int i = 0; i < 7; ++i) *dst[i] = reinterpret_cast<double *>(s->din_block + s->in_off[i]);
+  if (off <= kPinnedMirrorBytes) {
+    // (failure to page-lock is not an error: the solve falls back to the seven separate copies)
+    if (hipHostMalloc(reinterpret_cast<void **>(&s->hin_block), off, hipHostMallocDefault) != hipSuccess) s->hin_block = nullptr;
+  }
   return FCCQP_OK;
 }
 
@@ -273,13 +293,28 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
     HIP_TRY(s, hipEventCreate(&s->ev1));
     HIP_TRY(s, hipEventCreateWithFlags(&s->ev2, hipEventDisableTiming));
     const size_t B = (size_t)batch, n = (size_t)num_vars;
-    HIP_TRY(s, dmalloc(&s->dx, B * n));
+    {
+      // z (= x), metrics, factor ticks, n_iter, flags: one block, so that GetSolution is one copy
+      const size_t bytes[5] = {sizeof(double) * (B * n ? B * n : 1), sizeof(double) * 4 * B, sizeof(long long) * B,
+                               sizeof(int) * B, sizeof(int) * B};
+      size_t off = 0;
+      for (int i = 0; i < 5; ++i) {
+        s->res_off[i] = off;
+        off += align256(bytes[i]);
+      }
+      s->res_bytes = off;
+      HIP_TRY(s, dmalloc(&s->dres_block, off));
+      s->dx = reinterpret_cast<double *>(s->dres_block + s->res_off[0]);
+      s->dmetrics = reinterpret_cast<double *>(s->dres_block + s->res_off[1]);
+      s->dticks = reinterpret_cast<long long *>(s->dres_block + s->res_off[2]);
+      s->dniter = reinterpret_cast<int *>(s->dres_block + s->res_off[3]);
+      s->dflags = reinterpret_cast<int *>(s->dres_block + s->res_off[4]);
+      if (off <= kPinnedMirrorBytes &&
+          hipHostMalloc(reinterpret_cast<void **>(&s->hres_block), off, hipHostMallocDefault) != hipSuccess)
+        s->hres_block = nullptr;
+    }
     HIP_TRY(s, dmalloc(&s->dmux, B * n));
     HIP_TRY(s, dmalloc(&s->dmulc, B * (size_t)nc));
-    HIP_TRY(s, dmalloc(&s->dmetrics, 4 * B));
-    HIP_TRY(s, dmalloc(&s->dniter, B));
-    HIP_TRY(s, dmalloc(&s->dflags, B));
-    HIP_TRY(s, dmalloc(&s->dticks, B));
     // reference ctor zero-initialises x_, mu_x_, mu_lambda_c_ (src/fcc_qp.cpp:48-53)
     HIP_TRY(s, hipMemset(s->dx, 0, sizeof(double) * (B * n ? B * n : 1)));
     HIP_TRY(s, hipMemset(s->dmux, 0, sizeof(double) * (B * n ? B * n : 1)));
@@ -317,11 +352,12 @@ int fccqp_destroy(fccqp_solver *s) {
   if (!s) return FCCQP_OK;
   DeviceGuard g(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  void *ptrs[] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, s->dx, s->dmux, s->dmulc,
-                  s->dmetrics, s->dwork, s->dniter, s->dflags, s->dticks, s->dphase, s->dfb_list,
-                  s->dfb_count, s->dcod_ws};
+  void *ptrs[] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub, s->din_block, s->dres_block, s->dmux, s->dmulc,
+                  s->dwork, s->dphase, s->dfb_list, s->dfb_count, s->dcod_ws};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (s->hin_block) (void)hipHostFree(s->hin_block);
+  if (s->hres_block) (void)hipHostFree(s->hres_block);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev2) (void)hipEventDestroy(s->ev2);
@@ -436,6 +472,31 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
   int rc = ensure_staging(s);
   if (rc != FCCQP_OK) return rc;
   hipStream_t st = s->stream;
+  if (s->hin_block) {
+    // small batch: gather into the page-locked mirror, one copy.  (The previous solve has finished reading
+    // the mirror's device twin only when its kernel is done; the mirror itself is free once its copy is.)
+    if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+    char *h = s->hin_block;
+    std::memcpy(h + s->in_off[0], Q, sizeof(double) * B * n * n);
+    std::memcpy(h + s->in_off[1], b, sizeof(double) * B * n);
+    if (m * n) std::memcpy(h + s->in_off[2], A_eq, sizeof(double) * B * m * n);
+    if (m) std::memcpy(h + s->in_off[3], b_eq, sizeof(double) * B * m);
+    for (size_t i = 0; i < B && nm; ++i)    // keep the first nc/3 of every instance's row
+      std::memcpy(h + s->in_off[4] + sizeof(double) * nm * i, friction_coeffs + (size_t)n_friction * i, sizeof(double) * nm);
+    std::memcpy(h + s->in_off[5], lb, sizeof(double) * B * n);
+    std::memcpy(h + s->in_off[6], ub, sizeof(double) * B * n);
+    HIP_TRY(s, hipMemcpyAsync(s->din_block, h, s->in_bytes, hipMemcpyHostToDevice, st));
+    rc = enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st);
+    if (rc != FCCQP_OK) return rc;
+    if (!wait) {
+      s->last_solve_wall = 0.0;
+      return FCCQP_OK;
+    }
+    HIP_TRY(s, hipStreamSynchronize(st));
+    const auto t1s = std::chrono::high_resolution_clock::now();
+    s->last_solve_wall = std::chrono::duration<double>(t1s - t0).count();  // src/fcc_qp.cpp:188-190
+    return FCCQP_OK;
+  }
   HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(double) * B * n * n, hipMemcpyHostToDevice, st));
   HIP_TRY(s, hipMemcpyAsync(s->db, b, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
   if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(double) * B * m * n, hipMemcpyHostToDevice, st));
@@ -551,15 +612,28 @@ int fccqp_get_solution(fccqp_solver *s, double *z, fccqp_details *details) {
   DeviceGuard g(s->device);
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   const size_t B = (size_t)s->batch, n = (size_t)s->n;
-  if (z && n) HIP_TRY(s, hipMemcpy(z, s->dx, sizeof(double) * B * n, hipMemcpyDeviceToHost));
+  const bool one_copy = s->hres_block != nullptr;
+  if (one_copy) {   // small batch: the whole result block in one copy into page-locked memory
+    HIP_TRY(s, hipMemcpy(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost));
+    if (z && n) std::memcpy(z, s->hres_block + s->res_off[0], sizeof(double) * B * n);
+  } else if (z && n) {
+    HIP_TRY(s, hipMemcpy(z, s->dx, sizeof(double) * B * n, hipMemcpyDeviceToHost));
+  }
   if (details) {
     std::vector<int> it(B), fl(B);
     std::vector<double> met(4 * B);
     std::vector<long long> tk(B);
-    HIP_TRY(s, hipMemcpy(it.data(), s->dniter, sizeof(int) * B, hipMemcpyDeviceToHost));
-    HIP_TRY(s, hipMemcpy(fl.data(), s->dflags, sizeof(int) * B, hipMemcpyDeviceToHost));
-    HIP_TRY(s, hipMemcpy(met.data(), s->dmetrics, sizeof(double) * 4 * B, hipMemcpyDeviceToHost));
-    HIP_TRY(s, hipMemcpy(tk.data(), s->dticks, sizeof(long long) * B, hipMemcpyDeviceToHost));
+    if (one_copy) {
+      std::memcpy(met.data(), s->hres_block + s->res_off[1], sizeof(double) * 4 * B);
+      std::memcpy(tk.data(), s->hres_block + s->res_off[2], sizeof(long long) * B);
+      std::memcpy(it.data(), s->hres_block + s->res_off[3], sizeof(int) * B);
+      std::memcpy(fl.data(), s->hres_block + s->res_off[4], sizeof(int) * B);
+    } else {
+      HIP_TRY(s, hipMemcpy(it.data(), s->dniter, sizeof(int) * B, hipMemcpyDeviceToHost));
+      HIP_TRY(s, hipMemcpy(fl.data(), s->dflags, sizeof(int) * B, hipMemcpyDeviceToHost));
+      HIP_TRY(s, hipMemcpy(met.data(), s->dmetrics, sizeof(double) * 4 * B, hipMemcpyDeviceToHost));
+      HIP_TRY(s, hipMemcpy(tk.data(), s->dticks, sizeof(long long) * B, hipMemcpyDeviceToHost));
+    }
     double wall = s->last_solve_wall;
     if (wall == 0.0) {  // device-pointer solve: report the kernel time instead
       float ms = 0.f;

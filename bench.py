@@ -222,26 +222,34 @@ def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup
     # BASELINE configs[3]: 36-DoF / 8-contact shape (generic kernel, four waves per QP)
     run("large_shape", P.LARGE, "W-sat", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
     out["end_to_end"] = end_to_end(P, O, dev_index, log)
+    out["end_to_end_f32"] = end_to_end(P, O, dev_index, log, f32=True)
     return out
 
 
-def end_to_end(P, O, dev_index, log, handles=3, rounds=12):
+def end_to_end(P, O, dev_index, log, handles=3, rounds=12, f32=False):
     """Host memory in, host memory out (SURVEY.md 8d timing protocol): page-locked input and result
     buffers, `handles` solver handles round-robin so that the H2D copy of one batch, the kernel of
     another and the D2H copy of z of a third overlap (fccqp_solve_async / fccqp_get_z_async).  Per
     4096-batch 202 MB cross PCIe: this rate is bounded by the link, not by the kernel, and is never
-    the headline `value`."""
+    the headline `value`.  f32: the inputs are float32 arrays (BASELINE configs[2]: fp32 is a storage
+    format -- widened on load, arithmetic and z in fp64) through fccqp_solve_async_f32: half the bytes."""
     import numpy as np
     from tests import capi as C
     L = C.lib()
     dp = ctypes.POINTER(ctypes.c_double)
+    fp = ctypes.POINTER(ctypes.c_float)
     L.fccqp_solve_async.argtypes = [ctypes.c_void_p, dp, dp, dp, dp, dp, ctypes.c_int, dp, dp]
+    L.fccqp_solve_async_f32.argtypes = [ctypes.c_void_p, fp, fp, fp, fp, fp, ctypes.c_int, fp, fp]
     L.fccqp_get_z_async.argtypes = [ctypes.c_void_p, dp]
     L.fccqp_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     L.fccqp_host_unregister.argtypes = [ctypes.c_void_p]
     nb, shape, options = BATCH_PER_GPU, P.WALKING, P.HARNESS_OPTIONS
     batch = P.workload("W-sat", nb, shape, distinct=256)
-    ins = [[np.ascontiguousarray(a.copy()) for a in batch.arrays()] for _ in range(handles)]
+    if f32:
+        ins = [[np.ascontiguousarray(a.astype(np.float32)) for a in batch.arrays()] for _ in range(handles)]
+        batch = P.Batch(*(a.astype(np.float64) for a in ins[0]))       # the oracle sees the rounded values
+    else:
+        ins = [[np.ascontiguousarray(a.copy()) for a in batch.arrays()] for _ in range(handles)]
     zs = [np.zeros((nb, shape.n)) for _ in range(handles)]
     solvers = [C.Solver(*shape.ctor_args, batch=nb, device=dev_index) for _ in range(handles)]
     pinned = []
@@ -255,7 +263,11 @@ def end_to_end(P, O, dev_index, log, handles=3, rounds=12):
 
     def submit(k):
         a = ins[k]
-        rc = L.fccqp_solve_async(solvers[k].h, C._p(a[0]), C._p(a[1]), C._p(a[2]), C._p(a[3]), C._p(a[4]), nf, C._p(a[5]), C._p(a[6]))
+        if f32:
+            q = [x.ctypes.data_as(fp) for x in a]
+            rc = L.fccqp_solve_async_f32(solvers[k].h, q[0], q[1], q[2], q[3], q[4], nf, q[5], q[6])
+        else:
+            rc = L.fccqp_solve_async(solvers[k].h, C._p(a[0]), C._p(a[1]), C._p(a[2]), C._p(a[3]), C._p(a[4]), nf, C._p(a[5]), C._p(a[6]))
         rc = rc or L.fccqp_get_z_async(solvers[k].h, C._p(zs[k]))
         if rc != C.OK:
             raise RuntimeError(f"async solve failed: {rc}")
@@ -285,7 +297,9 @@ def end_to_end(P, O, dev_index, log, handles=3, rounds=12):
            "pcie_gb_per_s": bytes_per_batch * done / wall / 1e9, "host_bytes_per_batch": bytes_per_batch,
            "parity": {"sample": 64, "max_rel_err": err},
            "what": "page-locked host buffers -> H2D + kernel + D2H of z, batches pipelined over the handles"}
-    log(f"[bench] end_to_end: {rec['value'] / 1e6:.3f} M solves/s, {rec['pcie_gb_per_s']:.1f} GB/s over PCIe, max rel err {err:.1e}")
+    if f32:
+        rec["what"] = "float32 inputs, " + rec["what"]
+    log(f"[bench] end_to_end{'_f32' if f32 else ''}: {rec['value'] / 1e6:.3f} M solves/s, {rec['pcie_gb_per_s']:.1f} GB/s over PCIe, max rel err {err:.1e}")
     return rec
 
 

@@ -539,6 +539,40 @@ int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, cons
   return enqueue(s, dQ, db, dA_eq, db_eq, dfriction, dlb, dub, st);
 }
 
+int fccqp_solve_async_f32(fccqp_solver *s, const float *Q, const float *b, const float *A_eq,
+                          const float *b_eq, const float *friction_coeffs, int n_friction,
+                          const float *lb, const float *ub) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  const size_t B = (size_t)s->batch, n = (size_t)s->n, m = (size_t)s->m, nm = n_mu(s);
+  if ((n && (!Q || !b || !lb || !ub)) || (m && n && !A_eq) || (m && !b_eq) || (nm && !friction_coeffs))
+    return fail(s, FCCQP_ERR_INVALID_ARG, "null input pointer");
+  if (n_friction != (int)nm) return fail(s, FCCQP_ERR_FRICTION_COEFFS, "n_friction must equal nc/3 here");
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(s, FCCQP_ERR_NO_DEVICE, "hipSetDevice failed");
+  int rc = ensure_staging(s);
+  if (rc != FCCQP_OK) return rc;
+  rc = ensure_vec_staging(s);
+  if (rc != FCCQP_OK) return rc;
+  hipStream_t st = s->stream;
+  // Everything travels as float.  Q and A_eq land in the front halves of their f64 staging buffers and
+  // are read there by the kernel; the five small vectors land in the unused back half of Q's buffer
+  // (B n^2 floats: far more than B (3n + m + nc/3)) and are widened on the device.
+  float *const back = reinterpret_cast<float *>(s->dQ) + B * n * n;
+  float *const dv[5] = {back, back + B * n, back + B * (n + m), back + B * (n + m + nm), back + B * (2 * n + m + nm)};
+  const float *const hv[5] = {b, b_eq, friction_coeffs, lb, ub};
+  const size_t cnt[5] = {B * n, B * m, B * nm, B * n, B * n};
+  if (B * (3 * n + m + nm) > B * n * n) return fail(s, FCCQP_ERR_UNSUPPORTED, "shape too small for the float staging layout");
+  HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));
+  if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(float) * B * m * n, hipMemcpyHostToDevice, st));
+  for (int i = 0; i < 5; ++i)
+    if (cnt[i]) HIP_TRY(s, hipMemcpyAsync(dv[i], hv[i], sizeof(float) * cnt[i], hipMemcpyHostToDevice, st));
+  const float *const src[5] = {dv[0], dv[1], dv[2], dv[3], dv[4]};
+  double *const dst[5] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub};
+  HIP_TRY(s, fccqp::launch_widen5(src, dst, cnt, st));
+  s->last_solve_wall = 0.0;   // reported as the kernel time, like a device-pointer solve
+  return enqueue(s, s->dQ, s->wb, s->dA, s->wbeq, s->wmu, s->wlb, s->wub, st, /*qa_f32=*/true);
+}
+
 int fccqp_solve_device_f32(fccqp_solver *s, const float *dQ, const float *db, const float *dA_eq,
                            const float *db_eq, const float *dfriction, const float *dlb,
                            const float *dub, void *stream) {

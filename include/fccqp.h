@@ -146,6 +146,13 @@ int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double 
 int fccqp_solve_async(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
                       const double *b_eq, const double *friction_coeffs, int n_friction,
                       const double *lb, const double *ub);
+/* The same for fp32-STORAGE inputs (see fccqp_solve_f32 below): all seven arrays travel as float -- half the
+ * PCIe bytes of the fp64 form, which is what bounds a host-fed pipeline -- and the small vectors are widened
+ * on the device.  Results are bit-identical to fccqp_solve_f32 on the same arrays.  Shapes with
+ * num_vars^2 < 3 num_vars + num_equality_constraints + nc/3 are not supported here (FCCQP_ERR_UNSUPPORTED). */
+int fccqp_solve_async_f32(fccqp_solver *s, const float *Q, const float *b, const float *A_eq,
+                          const float *b_eq, const float *friction_coeffs, int n_friction,
+                          const float *lb, const float *ub);
 /* Page-lock / release a host range for DMA (thin wrappers over hipHostRegister/Unregister, so
  * that a caller of this ABI needs no HIP headers).  The reference has no counterpart: its inputs
  * never leave the host (src/fcc_qp.cpp:146-150 copies them into Eigen members). */

@@ -281,6 +281,27 @@ def test_sharded_solve_equals_unsharded_bit_for_bit(oracle):
             F.FCCQPSharded(60, 38, 12, 38, 8, [0, 1])          # no such device
 
 
+def test_async_f32_host_solve_equals_the_synchronous_f32_path():
+    """fccqp_solve_async_f32: float32 arrays all the way to the device, small vectors widened there --
+    bit-identical to fccqp_solve_f32 (host-side widening) on the same arrays."""
+    import ctypes
+    from tests import capi as C
+    L = C.lib()
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.fccqp_solve_async_f32.argtypes = [ctypes.c_void_p, fp, fp, fp, fp, fp, ctypes.c_int, fp, fp]
+    nb = 48
+    B = P.workload("W-mix", nb, P.WALKING)
+    f32 = [np.ascontiguousarray(a.astype(np.float32)) for a in B.arrays()]
+    s = C.Solver(*P.WALKING.ctor_args, batch=nb); s.set_options(**P.HARNESS_OPTIONS)
+    s.solve_f32_ok(*f32); z_sync, d_sync = s.solution()
+    q = [x.ctypes.data_as(fp) for x in f32]
+    assert L.fccqp_solve_async_f32(s.h, q[0], q[1], q[2], q[3], q[4], P.WALKING.nc // 3, q[5], q[6]) == C.OK
+    z_async, d_async = s.solution()
+    assert np.array_equal(z_async, z_sync)
+    assert [x.n_iter for x in d_async] == [x.n_iter for x in d_sync]
+    assert L.fccqp_solve_async_f32(s.h, q[0], q[1], q[2], q[3], q[4], 3, q[5], q[6]) != C.OK     # n_friction must be nc/3
+
+
 def test_async_host_solve_from_pinned_memory(oracle):
     """fccqp_solve_async + fccqp_get_z_async on page-locked buffers: two handles in flight, results
     equal to the synchronous path."""

@@ -439,21 +439,27 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) zc[bb] = Eb[((c < n) ? c : 0) * (NB + 1) + 1 + bb];
       }
+      // (a tile that lies wholly inside the n x n block needs no masks: I and J are constants here)
+      const bool interior = (16 * I + 15 < n) && (16 * J + 15 < n);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * I + grp + 4 * r, c = 16 * J + col;     // Gt[I][J][r] = (K1^-1)[row][c]
         double gv = Gt[I][J][r];
         if constexpr (NB > 0) {
 #pragma unroll
-          for (int bb = 0; bb < NB; ++bb) gv += corr_r[I][r][bb] * zc[bb];
+          for (int bb = 0; bb < NB; ++bb) gv = fma(corr_r[I][r][bb], zc[bb], gv);
         }
         const double g = rho * gv;
-        if (row < n && c < n) {
+        const bool inside = interior || (row < n && c < n);
+        if (inside) {
           M[row * n + c] = g;
           if (J != I) M[c * n + row] = g;                            // the mirror tile
         }
         if (NB == 0 && J == cbd && c == n && row < n) vbuf[row] = Gt[I][J][r];     // x_c
-        if (J < NW) Wt[I][J][r] = (row < n && c < n) ? (((row == c) ? 1.0 : 0.0) - g) : ((row == c) ? 1.0 : 0.0);
+        if (J < NW) {
+          const double unit = (I == J && row == c) ? 1.0 : 0.0;
+          Wt[I][J][r] = inside ? unit - g : unit;
+        }
       }
     }
   }
@@ -1242,9 +1248,8 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       lds_fence();
     };
     if (max_iter > 0) exchange_w();
-    // the loop header on an instruction-cache line boundary: the time per iteration moved by 5 % with
-    // nothing but the placement of the (otherwise identical) loop in the code
-    asm volatile(".p2align 8");
+    // (the build aligns loop headers to 256 bytes, -falign-loops: the time per iteration moved by 5 % with
+    // nothing but the placement of this -- otherwise identical -- loop in the code)
 #pragma nounroll
     for (int iter = 0; iter < max_iter; ++iter) {
       double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0};

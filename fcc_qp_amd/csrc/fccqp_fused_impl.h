@@ -821,9 +821,13 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
         if (col < kValid) {
           const int jcol = 16 * P + col, cb = SW::cbase(jcol);
           M[cb + jcol] = rmine;
+          // (entries above the diagonal go to a per-lane dummy slot of the dead exchange tile: one select
+          // of the address instead of an exec-mask round trip per store)
 #pragma unroll
-          for (int i = 1; i < kValid; ++i)
-            if (i > col) M[cb + 16 * P + i] = -T[i];
+          for (int i = 1; i < kValid; ++i) {
+            lds_f64 *dst = (i > col) ? M + cb + 16 * P + i : Sblk + col;
+            *dst = -T[i];
+          }
         }
       }
       lds_fence();
@@ -846,7 +850,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jrow = 16 * P + grp + 4 * r, irow = 16 * J + col;
-        if (irow < n) M[SW::cbase(jrow) + irow] = t[r] * rv[r];      // (jrow < n: P < J)
+        if (16 * J + 15 < n || irow < n) M[SW::cbase(jrow) + irow] = t[r] * rv[r];      // (jrow < n: P < J)
       }
     }
 #pragma unroll

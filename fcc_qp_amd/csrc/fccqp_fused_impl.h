@@ -775,7 +775,7 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
 }
 
 // W = U^T D U by register tiles (the presolve, see fused_kernel), same scheme as tile_factor_forward without
-// right-hand sides; the factor is WRITTEN to LDS in the packed layout solve_lds reads (L = U^T below the
+// right-hand sides; the factor is WRITTEN to LDS in the packed layout solve_lds_one_slot reads (L = U^T below the
 // diagonal, 1/d in the diagonal slots).  Returns true if a pivot was not above min_pivot (or not finite): W is
 // positive definite unless K is singular to working precision.
 // The exchange scratch sits behind the packed n x n image.
@@ -868,100 +868,61 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
   return bad;
 }
 
-// x := (L D L^T)^-1 x with M as left by tile_factor_store (L below the diagonal, 1/d in the diagonal slots);
-// x0/x1 are this lane's rows lane / 64+lane.
-// Column-oriented forward and backward substitution.  The only dependent chain is
-// v_readlane(x_k) -> fma; the L operands of four steps are fetched ahead of it, unconditionally
-// (clamped rows, masked by a select) and through running column offsets, so a step is ~11
-// instructions and no branch.  Rows of idle lanes carry garbage that is never broadcast or stored.
+// x := (L D L^T)^-1 x for N <= 64 (one row per lane), M as left by tile_factor_store.  Column-oriented forward
+// and backward substitution; the only dependent chain is v_readlane(x_k) -> fma.  The L operands of the next
+// U steps are fetched while the current U run (two register buffers): the single-buffered version waited
+// for an LDS round trip in front of every group of four steps.
 template <class SH>
-__device__ __forceinline__ void solve_lds(const lds_f64 *M, const int lane, double &x0, double &x1) {
-  constexpr int N = SH::N, U = 4;
-  constexpr int NA = (N < kWave) ? N : kWave;   // columns whose x_k lives in slot 0
-  const int row0 = lane, row1 = kWave + lane;
-  const int r0c = (row0 < N) ? row0 : N - 1, r1c = (row1 < N) ? row1 : N - 1;
-  const int cb0 = SH::cbase(r0c), cb1 = SH::cbase(r1c);
-  // ---- forward, unit lower: x_i -= L[i][k] x_k, i > k ----------------------------------------
+__device__ __forceinline__ void solve_lds_one_slot(const lds_f64 *M, const int lane, double &x) {
+  constexpr int N = SH::N, U = 8;
+  static_assert(N <= kWave, "one row per lane");
+  const int row = lane;
+  const int rc = (row < N) ? row : N - 1;        // clamped: in-bounds reads for idle lanes
+  const int cbr = SH::cbase(rc);
+  // ---- forward, unit lower: x_i -= L[i][k] x_k, i > k.  L[row][k] = M[cbase(k) + row] -------------------------
   {
-    int cb = SH::cbase(0);
+    double cur[U], nxt[U];
+    auto load_fwd = [&](double (&buf)[U], const int k0) {
 #pragma unroll
-    for (int k0 = 0; k0 < NA; k0 += U) {   // x_k from slot 0; both slots have rows below
-      double a0[U], a1[U];
-      int cbu = cb;
+      for (int u = 0; u < U; ++u) buf[u] = M[SH::cbase((k0 + u < N) ? k0 + u : N - 1) + rc];
+    };
+    load_fwd(cur, 0);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double l0 = M[cbu + r0c], l1 = M[cbu + r1c];
-        a0[u] = (row0 > k0 + u && k0 + u < NA) ? l0 : 0.0;
-        a1[u] = (k0 + u < NA) ? l1 : 0.0;
-        if (k0 + u + 1 < N) cbu += SH::cstep(k0 + u);
-      }
-      cb = cbu;
+    for (int k0 = 0; k0 < N; k0 += U) {
+      if (k0 + U < N) load_fwd(nxt, k0 + U);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const double xk = bcast_lane(x0, (k0 + u < NA) ? k0 + u : 0);
-        x0 = fma(-a0[u], xk, x0);
-        if constexpr (N > kWave) x1 = fma(-a1[u], xk, x1);
+        const int k = k0 + u;
+        const double a = (row > k && k < N) ? cur[u] : 0.0;
+        const double xk = bcast_lane(x, (k < N) ? k : 0);
+        x = fma(-a, xk, x);
       }
-    }
-    if constexpr (N > kWave) {
-      cb = SH::cbase(kWave);
 #pragma unroll
-      for (int k0 = kWave; k0 < N; k0 += U) {   // x_k from slot 1; only slot 1 has rows below
-        double a1[U];
-        int cbu = cb;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const double l1 = M[cbu + r1c];
-          a1[u] = (row1 > k0 + u && k0 + u < N) ? l1 : 0.0;
-          if (k0 + u + 1 < N) cbu += SH::cstep(k0 + u);
-        }
-        cb = cbu;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const double xk = bcast_lane(x1, (k0 + u < N) ? k0 + u - kWave : 0);
-          x1 = fma(-a1[u], xk, x1);
-        }
-      }
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
   }
-  // ---- D^-1: the diagonal slot holds 1/d with Eigen's pseudo-inverse rule folded in -----------
-  x0 *= M[cb0 + r0c];
-  if constexpr (N > kWave) x1 *= M[cb1 + r1c];
-  // ---- backward with L^T: x_i -= L[k][i] x_k, i < k (row k of L: a gather along lane columns) --
-  if constexpr (N > kWave) {
+  // ---- D^-1: the diagonal slot holds 1/d with Eigen's pseudo-inverse rule folded in -----------------------
+  x *= M[cbr + rc];
+  // ---- backward with L^T: x_i -= L[k][i] x_k, i < k.  L[k][row] = M[cbase(row) + k]: this lane's own column ---
+  {
+    double cur[U], nxt[U];
+    auto load_bwd = [&](double (&buf)[U], const int k0) {     // k = k0, k0 - 1, ...
 #pragma unroll
-    for (int k0 = N - 1; k0 >= kWave; k0 -= U) {   // x_k from slot 1; slot 0 rows are all above
-      double a0[U], a1[U];
+      for (int u = 0; u < U; ++u) buf[u] = M[cbr + ((k0 - u >= 1) ? k0 - u : 1)];
+    };
+    load_bwd(cur, N - 1);
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = (k0 - u >= kWave) ? k0 - u : kWave;
-        const double l0 = M[cb0 + k], l1 = M[cb1 + k];
-        a0[u] = (k0 - u >= kWave) ? l0 : 0.0;
-        a1[u] = (row1 < k && k0 - u >= kWave) ? l1 : 0.0;
-      }
+    for (int k0 = N - 1; k0 >= 1; k0 -= U) {
+      if (k0 - U >= 1) load_bwd(nxt, k0 - U);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = (k0 - u >= kWave) ? k0 - u : kWave;
-        const double xk = bcast_lane(x1, k - kWave);
-        x0 = fma(-a0[u], xk, x0);
-        x1 = fma(-a1[u], xk, x1);
+        const int k = k0 - u;
+        const double a = (k >= 1 && row < k) ? cur[u] : 0.0;
+        const double xk = bcast_lane(x, (k >= 1) ? k : 1);
+        x = fma(-a, xk, x);
       }
-    }
-  }
 #pragma unroll
-  for (int k0 = NA - 1; k0 >= 1; k0 -= U) {   // x_k from slot 0; only slot 0 has rows above
-    double a0[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = (k0 - u >= 1) ? k0 - u : 1;
-      const double l0 = M[cb0 + k];
-      a0[u] = (row0 < k && k0 - u >= 1) ? l0 : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = (k0 - u >= 1) ? k0 - u : 1;
-      const double xk = bcast_lane(x0, k);
-      x0 = fma(-a0[u], xk, x0);
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
   }
 }
@@ -1192,8 +1153,8 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       }
       // the solve runs in the natural layout (x_c is still in vbuf[0..n) from P3); its result goes
       // through vbuf to the lanes of the ADMM loop
-      double r0 = isnat ? vbuf[isnat ? lane : 0] : 0.0, r1 = 0.0;
-      solve_lds<SW>(M, lane, r0, r1);
+      double r0 = isnat ? vbuf[isnat ? lane : 0] : 0.0;
+      solve_lds_one_slot<SW>(M, lane, r0);
       lds_fence();
       vbuf[lane] = r0;
       lds_fence();

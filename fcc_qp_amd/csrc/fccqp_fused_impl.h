@@ -987,6 +987,19 @@ __device__ __forceinline__ void dpp_matvec(double (&acc)[kMvAcc], const double (
   }
 }
 
+// forces v[J .. NN) into (arch) VGPRs at this point of the program, ten at a time
+template <int J, int NN>
+__device__ __forceinline__ void pin_vgprs(double (&v)[NN]) {
+  if constexpr (J + 10 <= NN) {
+    asm volatile("" : "+v"(v[J]), "+v"(v[J + 1]), "+v"(v[J + 2]), "+v"(v[J + 3]), "+v"(v[J + 4]), "+v"(v[J + 5]), "+v"(v[J + 6]),
+                 "+v"(v[J + 7]), "+v"(v[J + 8]), "+v"(v[J + 9]));
+    pin_vgprs<J + 10>(v);
+  } else if constexpr (J < NN) {
+    asm volatile("" : "+v"(v[J]));
+    pin_vgprs<J + 1>(v);
+  }
+}
+
 // TIN: storage type of Q and A_eq (double, or float for the fp32-storage entry points: widened on
 // load).  A template parameter rather than a run-time flag: an extra code path in the assembly
 // phase perturbed the register allocation of the whole kernel (36 VGPR spills, +30% on the ADMM
@@ -1212,6 +1225,10 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];
       lds_fence();
     };
+    // rho G's row in ArchVGPRs from here on: its live range spans the presolve, where the allocator may park
+    // parts of it in AGPRs -- and then reads them back with v_accvgpr_read on EVERY iteration of the loop
+    // (seen once: 38.5 -> 44.7 us for the loop after an unrelated change upstream)
+    pin_vgprs<0>(Mrow);
     if (max_iter > 0) exchange_w();
     // (the build aligns loop headers to 256 bytes, -falign-loops: the time per iteration moved by 5 % with
     // nothing but the placement of this -- otherwise identical -- loop in the code)

@@ -5,11 +5,13 @@
 //   FCCQP::Solve   src/fcc_qp.cpp:114-191   FCCQP::DoADMM  src/fcc_qp.cpp:57-112
 //   projections    src/constraint_utils.cpp:5-65      Eigen LDLT call sites fcc_qp.cpp:68,86,161,174
 //
-// Why it looks the way it does (numbers from tools/fp64_issue_probe.hip and tools/lane_ops_probe.hip on MI355X):
-//   * one wave per SIMD: a v_fma_f64 issues every ~5.8 cycles whether or not it depends on the previous
-//     one, a v_mfma_f64_16x16x4 (1024 FMAs) every ~72-84 cycles: the matrix pipe is ~25 % cheaper per
-//     flop than the VALU (same 78.6 TFLOP/s peak), runs beside it, and -- what matters -- takes its
-//     operands ONE ELEMENT PER LANE and hands its result tile back as the next product's operand.
+// Why it looks the way it does (numbers from tools/fp64_issue_probe.hip, mfma_f64_probe.hip, vgpr_bank_probe.hip
+// and lane_ops_probe.hip on MI355X):
+//   * one wave per SIMD: a v_fma_f64 issues every 5.8-8.2 cycles (repeated / fresh register operands) whether
+//     or not it depends on the previous one, a v_mfma_f64_16x16x4 (1024 FMAs) every 64 cycles back to back:
+//     the matrix cores are the cheaper way to the same 78.6 TFLOP/s fp64 unit (they do NOT run beside the
+//     fp64 VALU: the two serialise), and -- what matters -- they take their operands ONE ELEMENT PER LANE
+//     and hand the result tile back as the next product's operand.
 //   * an operand every lane needs costs an LDS broadcast (2 LDS cycles per double per CU), a
 //     v_readlane pair (~9 cycles per double) -- or nothing: the fp64 ALU's one DPP mode, row_newbcast,
 //     lets an FMA read lane k of its 16-lane row.  Every sequential piece of the path (diagonal-tile

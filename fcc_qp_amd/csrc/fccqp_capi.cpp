@@ -62,6 +62,13 @@ struct fccqp_solver {
   // per instance up to a full grid, bounded by 256 MiB of COD workspace (2 N^2 doubles per block).
   int fb_blocks = 1;
   long long work_stride = 0;
+  // two-launch form of the fused kernel (FCCQP_KERNEL_FUSED_SPLIT): rows of rho G + x_c, allocated on first use
+  double *dsplit = nullptr;
+  long long split_stride = 0;
+  // -DFCCQP_TICKET_DISPATCH experiment (block_instance, fccqp_device.h): a counter that only grows and the
+  // ticket the next launch starts at
+  unsigned *dticket = nullptr;
+  unsigned ticket_base = 0;
   std::string err;
 };
 
@@ -173,17 +180,36 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
 
   const bool want_fused = s->kernel_request != FCCQP_KERNEL_GENERIC;
   const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s) && fccqp::fused_pointers_ok(a);
-  if (s->kernel_request == FCCQP_KERNEL_FUSED && !can_fuse)
+#ifdef FCCQP_TICKET_DISPATCH
+  // tickets only where a launch runs in several rounds (all workgroups of a smaller one are resident at once:
+  // 4 per CU of the fused kernel, at least 1 of the generic one)
+  const bool tickets = s->batch > ((want_fused && can_fuse) ? 1024 : 256);
+  a.ticket = tickets ? s->dticket : nullptr;
+  a.ticket_base = s->ticket_base;
+#endif
+  if ((s->kernel_request == FCCQP_KERNEL_FUSED || s->kernel_request == FCCQP_KERNEL_FUSED_SPLIT) && !can_fuse)
     return fail(s, FCCQP_ERR_UNSUPPORTED,
                 "no fused kernel for this shape");
+  // ADMM waves per SIMD of the two-launch form, 0: one launch
+  int split = 0;
+  if (want_fused && can_fuse && s->kernel_request == FCCQP_KERNEL_FUSED_SPLIT) {
+    static const int waves = [] { const char *e = std::getenv("FCCQP_SPLIT_WAVES"); return (e && e[0] == '3') ? 3 : 2; }();
+    if (!s->dsplit) {
+      s->split_stride = fccqp::fused_split_workspace_doubles(s->n);
+      HIP_TRY(s, dmalloc(&s->dsplit, (size_t)s->batch * (size_t)s->split_stride));
+    }
+    split = waves;
+  }
   // the handle's state (warm-start vectors, fallback list, counters, workspace) is shared by every
   // solve: a solve enqueued on another stream than the previous one waits for it on the device
   if (s->solved && stream != s->last_stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev1, 0));
   HIP_TRY(s, hipEventRecord(s->ev0, stream));
   hipError_t e;
   if (want_fused && can_fuse) {
-    s->kernel_used = FCCQP_KERNEL_FUSED;
-    e = fccqp::launch_fused(a, stream, qa_f32);
+    s->kernel_used = split ? FCCQP_KERNEL_FUSED_SPLIT : FCCQP_KERNEL_FUSED;
+    fccqp::KernelArgs af = a;
+    if (split) { af.workspace = s->dsplit; af.workspace_stride = s->split_stride; }
+    e = fccqp::launch_fused(af, stream, qa_f32, split);
   } else {
     s->kernel_used = FCCQP_KERNEL_GENERIC;
     if (!s->dwork && s->n > 0 && s->n <= 128) {
@@ -203,12 +229,18 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     e = fccqp::launch_generic(a, s->lds_limit, stream, qa_f32);
   }
   if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "kernel launch", e);
+#ifdef FCCQP_TICKET_DISPATCH
+  if (tickets) s->ticket_base += (unsigned)s->batch;      // every workgroup of the launch draws exactly one
+#endif
   if (fb) {
     // fallback launch over the (normally empty) device list: COD x0, then ADMM from it.  It also
     // zeroes the other counter, which the next solve's main kernel will append to.
     const int blocks = s->fb_blocks;
     fccqp::KernelArgs b = a;
     b.fb_list = nullptr; b.fb_count = nullptr;
+#ifdef FCCQP_TICKET_DISPATCH
+    b.ticket = nullptr;
+#endif
     b.inst_list = s->dfb_list; b.inst_count = cnt; b.next_count = cnt_next;
     e = fccqp::launch_generic_list(b, s->lds_limit, blocks, stream, qa_f32);
     if (e != hipSuccess) {
@@ -329,6 +361,10 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
     HIP_TRY(s, hipMemset(s->dfb_list, 0, sizeof(int) * (B + 2)));
     HIP_TRY(s, dmalloc(&s->dfb_count, 2));
     HIP_TRY(s, hipMemset(s->dfb_count, 0, 2 * sizeof(int)));
+#ifdef FCCQP_TICKET_DISPATCH
+    HIP_TRY(s, dmalloc(&s->dticket, 1));
+    HIP_TRY(s, hipMemset(s->dticket, 0, sizeof(unsigned)));
+#endif
     s->cod_stride = fccqp::cod_workspace_doubles_host(num_vars, num_equality_constraints);
     {
       long long blocks = batch < 1024 ? batch : 1024;
@@ -353,7 +389,7 @@ int fccqp_destroy(fccqp_solver *s) {
   DeviceGuard g(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   void *ptrs[] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub, s->din_block, s->dres_block, s->dmux, s->dmulc,
-                  s->dwork, s->dphase, s->dfb_list, s->dfb_count, s->dcod_ws};
+                  s->dwork, s->dphase, s->dfb_list, s->dfb_count, s->dcod_ws, s->dticket, s->dsplit};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->hin_block) (void)hipHostFree(s->hin_block);
@@ -384,7 +420,7 @@ int fccqp_set_warm_start(fccqp_solver *s, int warm_start) {
   return FCCQP_OK;
 }
 int fccqp_set_kernel(fccqp_solver *s, int kernel) {
-  if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_FUSED) return FCCQP_ERR_INVALID_ARG;
+  if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_FUSED_SPLIT) return FCCQP_ERR_INVALID_ARG;
   s->kernel_request = kernel;
   return FCCQP_OK;
 }
@@ -401,7 +437,8 @@ int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {
   }
   const bool fuse = s->kernel_request != FCCQP_KERNEL_GENERIC &&
                     fccqp::fused_supported(s->n, s->m, s->nc, s->s);
-  *kernel_in_use = fuse ? FCCQP_KERNEL_FUSED : FCCQP_KERNEL_GENERIC;
+  *kernel_in_use = fuse ? (s->kernel_request == FCCQP_KERNEL_FUSED_SPLIT ? FCCQP_KERNEL_FUSED_SPLIT : FCCQP_KERNEL_FUSED)
+                        : FCCQP_KERNEL_GENERIC;
   return FCCQP_OK;
 }
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc, int *lambda_c_start,

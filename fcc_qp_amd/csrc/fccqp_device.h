@@ -42,7 +42,56 @@ struct KernelArgs {
   long long *phase_ticks;  // optional [8][batch]: 100 MHz ticks per phase (fused kernel), or null
   double *workspace;      // generic kernel, large shapes: per-block packed KKT in global memory
   long long workspace_stride;  // doubles per block
+#ifdef FCCQP_TICKET_DISPATCH
+  // experiment (see block_instance below): every workgroup of a batch launch draws a ticket from *ticket, a
+  // counter that only ever grows; the launch's first ticket is ticket_base (the host adds the grid size after
+  // every launch, so nothing is zeroed between launches)
+  unsigned *ticket;
+  unsigned ticket_base;
+#endif
 };
+
+// Which instance a workgroup of a batch launch solves: a fixed pseudo-random permutation of blockIdx.x.
+// Workgroups are dealt round-robin over the eight XCDs (block b runs on XCD b % 8; every XCD takes its grid / 8
+// blocks in order) and, inside an XCD, onto its CUs in a fixed order too, so with instance = blockIdx.x a
+// workload whose cost is periodic in the instance index -- W-mix of fcc_qp_amd/problems.py: even instances leave
+// after one ADMM iteration, odd ones run all 100 -- puts the expensive instances on the same XCDs / CUs round after
+// round.  The permutation is a bijection of [0, batch) (an invertible integer hash on ceil(log2 batch) bits,
+// re-applied while it lands past the batch: cycle walking); results do not depend on it.  Returns -1 past the batch.
+//
+// Measured on MI355X (tools/dispatch_order.py, profiles/r03*_dispatch_order.json; walking shape, batch 4096, kernel
+// ms): W-mix in index order 0.407 with instance = blockIdx.x; 0.389 with the batch shuffled on the host; mixing
+// only the low three bits of the index into the XCD choice (b ^ ((b >> 3) & 7)): 0.404 -- the imbalance just moves
+// from the XCDs to the CUs of an XCD.  None of them reaches the 0.335 of a perfectly packed schedule: with four
+// rounds of 57 / 95 us jobs a greedy schedule ends about (longest job - mean remaining job) after the work runs
+// out, whatever the order.  A ticketed DYNAMIC map (-DFCCQP_TICKET_DISPATCH: one returning atomicAdd per workgroup,
+// instance = order of arrival) was built and measured too: 0.394-0.397 on W-mix, no better than a static shuffle
+// (each XCD still runs exactly grid / 8 workgroups), and 1.2 % slower on W-sat (the atomic's round trip sits in
+// front of the first load).  Off by default.
+__device__ __forceinline__ unsigned mix_bits(unsigned x, const unsigned mask, const int half) {
+  x ^= x >> half; x = (x * 0x9E3779B1u) & mask;
+  x ^= x >> half; x = (x * 0x85EBCA77u) & mask;
+  x ^= x >> half;
+  return x;
+}
+__device__ __forceinline__ int block_instance(const KernelArgs &a) {
+  unsigned t = blockIdx.x;
+#ifdef FCCQP_TICKET_DISPATCH
+  if (a.ticket) {
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ticket_base;
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+  }
+#endif
+  const unsigned batch = (unsigned)a.batch;
+  if (t >= batch) return -1;
+  if (batch >= 128u) {                                     // (smaller launches are resident all at once)
+    const int bits = 32 - __builtin_clz(batch - 1u);       // ceil(log2 batch), >= 7
+    const unsigned mask = (1u << bits) - 1u;
+    const int half = (bits + 1) >> 1;
+    do t = mix_bits(t, mask, half); while (t >= batch);    // cycle walking: expected < 2 rounds
+  }
+  return (int)t;
+}
 
 // flag bits (mirror include/fccqp.h)
 constexpr int kFlagPresolveRan = 1;
@@ -81,6 +130,11 @@ long long cod_workspace_doubles_host(int n, int m);
 // ---- fused shape-specialised kernels (fccqp_fused.hip) ---------------------------------------
 bool fused_supported(int n, int m, int nc, int s);
 bool fused_pointers_ok(const KernelArgs &a);  // (always true since the tile loader: natural alignment suffices)
-hipError_t launch_fused(const KernelArgs &a, hipStream_t stream, bool qa_f32);
+// split == 0: the whole solve in one launch.  split == 2 or 3: the two-launch form -- fused_kernel<.., SPLIT> up to
+// the presolve, then admm_kernel at `split` waves per SIMD; a.workspace must then hold
+// fused_split_workspace_doubles(n) doubles per instance (a.workspace_stride)
+hipError_t launch_fused(const KernelArgs &a, hipStream_t stream, bool qa_f32, int split);
+long long fused_split_workspace_doubles(int n);
+hipError_t launch_fused_split(const KernelArgs &a, hipStream_t stream, bool qa_f32, int waves_per_simd);
 
 }  // namespace fccqp

@@ -58,7 +58,8 @@ bool fused_pointers_ok(const KernelArgs &) {
   return true;
 }
 
-hipError_t launch_fused(const KernelArgs &a, hipStream_t stream, bool qa_f32) {
+hipError_t launch_fused(const KernelArgs &a, hipStream_t stream, bool qa_f32, int split) {
+  if (split != 0) return launch_fused_split(a, stream, qa_f32, split);     // fccqp_fused_split.hip
   return qa_f32 ? launch_fused_f32(a, stream) : launch_by_shape(a, stream);
 }
 #endif

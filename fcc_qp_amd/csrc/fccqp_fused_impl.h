@@ -1002,11 +1002,195 @@ __device__ __forceinline__ void pin_vgprs(double (&v)[NN]) {
   }
 }
 
+// ---- the per-lane roles of the ADMM layout (Shape::lane_variable) and the per-instance small vectors ----------
+template <class SH>
+struct AdmmLane {
+  int var, vi, cidx, ccomp;
+  bool isvar, is_cone;
+  const double *lbp, *ubp, *mup;
+  double *xs, *mux_s, *mulc_s;
+  __device__ __forceinline__ AdmmLane(const KernelArgs &a, const int inst, const int lane) {
+    constexpr int n = SH::n, nc = SH::nc;
+    var = SH::lane_variable(lane);
+    isvar = var >= 0;
+    vi = isvar ? var : 0;
+    is_cone = ((lane >> 2) < SH::kContacts) && ((lane & 3) < 3);
+    cidx = is_cone ? (lane >> 2) : 0;
+    ccomp = is_cone ? (lane & 3) : 0;
+    mup = a.mu + (size_t)inst * (nc / 3);
+    lbp = a.lb + (size_t)inst * n;
+    ubp = a.ub + (size_t)inst * n;
+    xs = a.x + (size_t)inst * n;
+    mux_s = a.mu_x + (size_t)inst * n;
+    mulc_s = a.mu_lc + (size_t)inst * nc;
+  }
+};
+// `fresh()` hides a pointer from CSE so that a load is redone at the point of use instead of its value being
+// kept in a register (or in scratch) across the factorisation
+__device__ __forceinline__ const double *fresh(const double *p) { asm volatile("" : "+s"(p)); return p; }
+
+// P4: ADMM iterations (fcc_qp.cpp:74-110) from x (the presolve's x0, or the warm-start state) with this lane's
+// row Mrow of rho G and entry xc of x_c; leaves the last iterate in x, the duals in the warm-start state.
+template <class SH>
+__device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmLane<SH> &L, const int lane, lds_f64 *vbuf,
+                                                double (&Mrow)[SH::n], const double xc, double &x, int &n_iter,
+                                                double &x_res_norm, double &lc_res_norm) {
+  constexpr int n = SH::n, s0 = SH::s;
+  const bool isvar = L.isvar, is_cone = L.is_cone;
+  const int var = L.var, vi = L.vi, cidx = L.cidx, ccomp = L.ccomp;
+  const double *lbp = L.lbp, *ubp = L.ubp, *mup = L.mup;
+  double *mux_s = L.mux_s, *mulc_s = L.mulc_s;
+  const double vlb = isvar ? fresh(lbp)[vi] : -HUGE_VAL;
+  const double vub = isvar ? fresh(ubp)[vi] : HUGE_VAL;
+  const double vmu = is_cone ? fresh(mup)[cidx] : 0.0;
+  double mux = 0.0, mulc = 0.0;
+  if (a.warm_start) {  // fcc_qp.cpp:136-139
+    mux = isvar ? mux_s[vi] : 0.0;
+    mulc = is_cone ? mulc_s[is_cone ? vi - s0 : 0] : 0.0;
+  }
+  double xbar = x, lcbar = x;  // :74-75
+  double xr = 0.0, lr = 0.0;
+  // The loop's wave-uniform operands (lane masks, the two eps) are re-made here as per-lane
+  // VGPR values: as SGPRs their live ranges span P3, the allocator spills them to VGPR lanes and
+  // the loop reloads each one with v_readlane pairs + wait states, several times per iteration;
+  // a VGPR copy costs one v_cmp per use at most (and is parked in an AGPR across P3 for free).
+  int var_i = isvar ? 1 : 0, cone_i = is_cone ? 1 : 0, z_i = (ccomp == 2) ? 1 : 0;
+  double eps_b = a.eps_bound, eps_f = a.eps_fcone;
+  const double vkc = cone_lane_constant(vmu, ccomp == 2);
+  asm volatile("" : "+v"(var_i), "+v"(cone_i), "+v"(z_i), "+v"(eps_b), "+v"(eps_f));
+  // w goes to vbuf[variable]; lanes without a variable write entry 63, which is no variable's (n < 64)
+  // and is never multiplied (the mat-vec stops at column n-1)
+  lds_f64 *const wslot = vbuf + (isvar ? var : kWave - 1);
+  // the trip count as a fresh SGPR: the kernarg copy's live range spans P3 and it is spilled to a VGPR
+  // lane, read back by v_readlane on every iteration
+  int max_iter = a.max_iter;
+  asm volatile("" : "+s"(max_iter));
+  n_iter = max_iter;           // :78
+  // x = x_c + (rho G) w   == the KKT solve of :83-87, this lane = row `var` of rho G.  Every lane needs all
+  // of w.  Reading it back as LDS broadcasts (ds_read_b128 of two doubles into all 64 lanes: a
+  // 1-KiB return per instruction) made the four waves of a CU wait on the LDS return path: 409 ns
+  // per mat-vec.  Instead each 16-lane row takes a copy of w, 16 entries per register
+  // (Wq[lane] = w[16 q + (lane & 15)]: NQ plain ds_read_b64), and the FMA itself fetches its
+  // operand from lane l of the row (v_fmac_f64 with the DPP control row_newbcast:l, the one DPP
+  // mode the fp64 ALU has): no LDS traffic, no extra instruction (tools/dpp_bench.hip).
+  // The write of w and the reads of its copies are issued at the END of an iteration, before the exit
+  // test, which then runs in the shadow of the LDS round trip (the wave's only one per iteration).
+  constexpr int NQ = (n + 15) / 16;
+  double Wq[NQ];
+  auto exchange_w = [&]() {
+    // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
+    const double w = (cone_i != 0) ? (lcbar - mulc) : (xbar - mux);
+    *wslot = w;
+    lds_fence();     // (one wave: its LDS operations complete in order; this is a compiler fence)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];
+    lds_fence();
+  };
+  // rho G's row in ArchVGPRs from here on: its live range spans the presolve, where the allocator may park
+  // parts of it in AGPRs -- and then reads them back with v_accvgpr_read on EVERY iteration of the loop
+  // (seen once: 38.5 -> 44.7 us for the loop after an unrelated change upstream)
+  pin_vgprs<0>(Mrow);
+  if (max_iter > 0) exchange_w();
+  // (the build aligns loop headers to 256 bytes, -falign-loops: the time per iteration moved by 5 % with
+  // nothing but the placement of this -- otherwise identical -- loop in the code)
+#pragma nounroll
+  for (int iter = 0; iter < max_iter; ++iter) {
+    double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0};
+    // the DPP read of a VGPR needs two wait states after a VALU write of it (the registers come
+    // straight from the LDS reads, but a copy could be scheduled in between): pin them here
+    if constexpr (NQ == 4) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]), "+v"(Wq[3]));
+    else if constexpr (NQ == 3) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]));
+    else if constexpr (NQ == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
+    else asm volatile("s_nop 1" : "+v"(Wq[0]));
+    dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
+    x = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in lanes 4c .. 4c+2 of
+    // this lane's quad: three quad_perm broadcasts (v_mov_b32 DPP pairs), no LDS round trip
+    const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused
+    const double cfx = quad_bcast<0>(xm), cfy = quad_bcast<1>(xm), cfz = quad_bcast<2>(xm);
+    // Every lane runs both updates, unmasked (a select per state variable per iteration otherwise).  A
+    // lane without a variable has x = mu_x = 0 and infinite bounds: it stays at zero.  Outside the
+    // contacts lcbar / lr / mulc are garbage that nothing reads: w, the exit test, the reported norms
+    // and the write-back all select on the lane's kind.
+    {
+      const double v = x + mux;
+      const double tt = min2(v, vub);   // std::min(x(i), ub(i))   constraint_utils.cpp:43
+      xbar = max2(tt, vlb);             // std::max(., lb(i))
+      xr = x - xbar;                    // :95
+      mux += xr;                        // :101
+    }
+    {
+      lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_i != 0);
+      lr = x - lcbar;                   // :96
+      mulc += lr;                       // :102
+    }
+    exchange_w();                       // for the next iteration (harmless after the last)
+    // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test
+    // is one ballot instead of two wave reductions; the norms themselves (:97-98) are only
+    // reported, and are reduced once after the loop.  An empty contact set has norm 0.
+    // (bitwise, not short-circuit: lane masks combined with scalar instructions, no branches)
+    const bool fail = ((var_i != 0) & !(fabs(xr) < eps_b)) | ((cone_i != 0) & !(fabs(lr) < eps_f));
+    if (__builtin_amdgcn_ballot_w64(fail) == 0) {
+      n_iter = iter;
+      break;
+    }
+  }
+  if (a.max_iter > 0) {
+    // :97-98  abs(max(maxCoeff, -minCoeff)) == max_i |r_i| of the last iteration executed
+    x_res_norm = wave_max(isvar ? fabs(xr) : 0.0);
+    lc_res_norm = wave_max(is_cone ? fabs(lr) : 0.0);
+  }
+  // duals are part of the warm-start state (fcc_qp.hpp:149-150)
+  if (isvar) mux_s[vi] = mux;
+  if (is_cone) mulc_s[vi - s0] = mulc;
+}
+
+// P5: epilogue metrics (fcc_qp.cpp:184-186) and write-back of z and the per-instance details
+template <class SH>
+__device__ __forceinline__ void epilogue_writeback(const KernelArgs &a, const AdmmLane<SH> &L, const int inst, const int lane,
+                                                   const double x, const int n_iter, const int flags,
+                                                   const double x_res_norm, const double lc_res_norm) {
+  const bool isvar = L.isvar, is_cone = L.is_cone;
+  const int vi = L.vi, cidx = L.cidx, ccomp = L.ccomp;
+  const double *lbp = L.lbp, *ubp = L.ubp, *mup = L.mup;
+  double *xs = L.xs;
+  lds_fence();
+  const double ffy = quad_bcast<1>(x), ffz = quad_bcast<2>(x);   // this quad's contact force
+  double bv = 0.0, cv = 0.0;
+  if (isvar) {
+    const double tt = min2(x, fresh(ubp)[vi]);
+    const double p = max2(tt, fresh(lbp)[vi]);
+    const double dd = x - p;
+    bv = dd * dd;                                        // constraint_utils.cpp:61-65
+  }
+  if (is_cone && ccomp == 0) {
+    const double fx = x, fy = ffy, fz = ffz;
+    const double v = sqrt(fx * fx + fy * fy) - fresh(mup)[cidx] * fz;
+    cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
+  }
+  bv = sqrt(wave_sum(bv));
+  cv = wave_sum(cv);
+
+  if (isvar) xs[vi] = x;
+  if (lane == 0) {
+    a.n_iter[inst] = n_iter;
+    a.flags[inst] = flags;
+    a.metrics[0 * (size_t)a.batch + inst] = x_res_norm;
+    a.metrics[1 * (size_t)a.batch + inst] = lc_res_norm;
+    a.metrics[2 * (size_t)a.batch + inst] = bv;
+    a.metrics[3 * (size_t)a.batch + inst] = cv;
+  }
+}
+
 // TIN: storage type of Q and A_eq (double, or float for the fp32-storage entry points: widened on
 // load).  A template parameter rather than a run-time flag: an extra code path in the assembly
 // phase perturbed the register allocation of the whole kernel (36 VGPR spills, +30% on the ADMM
 // loop), and even an unused extra kernarg field cost 3%.
-template <class SH, class TIN>
+//
+// SPLIT = true is the first half of the two-launch form (FCCQP_KERNEL_FUSED_SPLIT): the kernel ends after the
+// presolve and leaves this lane's row of rho G, x_c (workspace, lane-major: 512-byte stores) and x0 (the
+// warm-start state) for admm_kernel below, which runs P4 + P5 at two or three waves per SIMD.
+template <class SH, class TIN, bool SPLIT = false>
 __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   constexpr int n = SH::n, m = SH::m, nc = SH::nc, s0 = SH::s, N = SH::N;
   __shared__ __attribute__((aligned(16))) double lds_raw[SH::kLdsDoubles];
@@ -1014,19 +1198,14 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   lds_f64 *const vbuf = M + SH::kMat;
 
   const int lane = threadIdx.x;
-  const int inst = blockIdx.x;
-  if (inst >= a.batch) return;
+  const int inst = block_instance(a);     // block -> instance map (fccqp_device.h)
+  if (inst < 0) return;
 
   const TIN *__restrict__ Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
   const TIN *__restrict__ A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * m * n;
   const double *__restrict__ bq = a.b + (size_t)inst * n;
   const double *__restrict__ beq = a.b_eq + (size_t)inst * m;
-  const double *__restrict__ mup = a.mu + (size_t)inst * (nc / 3);
-  const double *__restrict__ lbp = a.lb + (size_t)inst * n;
-  const double *__restrict__ ubp = a.ub + (size_t)inst * n;
   double *xs = a.x + (size_t)inst * n;
-  double *mux_s = a.mu_x + (size_t)inst * n;
-  double *mulc_s = a.mu_lc + (size_t)inst * nc;
 
   // ---- vectors.  Two lane <-> variable maps: the natural one (lane i <-> variable i, i < n; lane r <->
   // equality row r) for the right-hand side and the presolve solve, and
@@ -1034,15 +1213,11 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   // The small vectors (b, b_eq, lb, ub, mu, warm-start state) are fetched from global memory at
   // the point of use instead of being held in registers across the phases: the factorisation needs
   // nearly the whole register file, and anything live across it is spilled to scratch and reloaded inside
-  // the ADMM loop.  `fresh()` hides the pointer from CSE so the loads really are redone.
-  auto fresh = [](const double *p) { asm volatile("" : "+s"(p)); return p; };
+  // the ADMM loop (AdmmLane, fresh()).
   const bool isnat = lane < n;
   const int var = SH::lane_variable(lane);
   const bool isvar = var >= 0;
   const int vi = isvar ? var : 0;
-  const bool is_cone = ((lane >> 2) < SH::kContacts) && ((lane & 3) < 3);
-  const int cidx = is_cone ? (lane >> 2) : 0;
-  const int ccomp = is_cone ? (lane & 3) : 0;
   double x = 0.0;
   if (a.warm_start) x = isvar ? xs[vi] : 0.0;  // fcc_qp.cpp:136-139 (duals are fetched at P4)
   // nc > 0: never the reference's equality-only case (fcc_qp.cpp:132-133)
@@ -1180,139 +1355,40 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       t4 = t5;
     }
 
-    // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------
-    const double vlb = isvar ? fresh(lbp)[vi] : -HUGE_VAL;
-    const double vub = isvar ? fresh(ubp)[vi] : HUGE_VAL;
-    const double vmu = is_cone ? fresh(mup)[cidx] : 0.0;
-    double mux = 0.0, mulc = 0.0;
-    if (a.warm_start) {  // fcc_qp.cpp:136-139
-      mux = isvar ? mux_s[vi] : 0.0;
-      mulc = is_cone ? mulc_s[is_cone ? vi - s0 : 0] : 0.0;
-    }
-    double xbar = x, lcbar = x;  // :74-75
-    double xr = 0.0, lr = 0.0;
-    // The loop's wave-uniform operands (lane masks, the two eps) are re-made here as per-lane
-    // VGPR values: as SGPRs their live ranges span P3, the allocator spills them to VGPR lanes and
-    // the loop reloads each one with v_readlane pairs + wait states, several times per iteration;
-    // a VGPR copy costs one v_cmp per use at most (and is parked in an AGPR across P3 for free).
-    int var_i = isvar ? 1 : 0, cone_i = is_cone ? 1 : 0, z_i = (ccomp == 2) ? 1 : 0;
-    double eps_b = a.eps_bound, eps_f = a.eps_fcone;
-    const double vkc = cone_lane_constant(vmu, ccomp == 2);
-    asm volatile("" : "+v"(var_i), "+v"(cone_i), "+v"(z_i), "+v"(eps_b), "+v"(eps_f));
-    // w goes to vbuf[variable]; lanes without a variable write entry 63, which is no variable's (n < 64)
-    // and is never multiplied (the mat-vec stops at column n-1)
-    lds_f64 *const wslot = vbuf + (isvar ? var : kWave - 1);
-    // the trip count as a fresh SGPR: the kernarg copy's live range spans P3 and it is spilled to a VGPR
-    // lane, read back by v_readlane on every iteration
-    int max_iter = a.max_iter;
-    asm volatile("" : "+s"(max_iter));
-    n_iter = max_iter;           // :78
-    // x = x_c + (rho G) w   == the KKT solve of :83-87, this lane = row `var` of rho G.  Every lane needs all
-    // of w.  Reading it back as LDS broadcasts (ds_read_b128 of two doubles into all 64 lanes: a
-    // 1-KiB return per instruction) made the four waves of a CU wait on the LDS return path: 409 ns
-    // per mat-vec.  Instead each 16-lane row takes a copy of w, 16 entries per register
-    // (Wq[lane] = w[16 q + (lane & 15)]: NQ plain ds_read_b64), and the FMA itself fetches its
-    // operand from lane l of the row (v_fmac_f64 with the DPP control row_newbcast:l, the one DPP
-    // mode the fp64 ALU has): no LDS traffic, no extra instruction (tools/dpp_bench.hip).
-    // The write of w and the reads of its copies are issued at the END of an iteration, before the exit
-    // test, which then runs in the shadow of the LDS round trip (the wave's only one per iteration).
-    constexpr int NQ = (n + 15) / 16;
-    double Wq[NQ];
-    auto exchange_w = [&]() {
-      // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
-      const double w = (cone_i != 0) ? (lcbar - mulc) : (xbar - mux);
-      *wslot = w;
-      lds_fence();     // (one wave: its LDS operations complete in order; this is a compiler fence)
+    if constexpr (SPLIT) {
+      // hand-over to admm_kernel: row `var` of rho G and x_c, lane-major (entry j of lane l at [j][l]); x0 goes
+      // to the warm-start state, which is where admm_kernel (like a warm start) takes x from
+      double *ws = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];
-      lds_fence();
-    };
-    // rho G's row in ArchVGPRs from here on: its live range spans the presolve, where the allocator may park
-    // parts of it in AGPRs -- and then reads them back with v_accvgpr_read on EVERY iteration of the loop
-    // (seen once: 38.5 -> 44.7 us for the loop after an unrelated change upstream)
-    pin_vgprs<0>(Mrow);
-    if (max_iter > 0) exchange_w();
-    // (the build aligns loop headers to 256 bytes, -falign-loops: the time per iteration moved by 5 % with
-    // nothing but the placement of this -- otherwise identical -- loop in the code)
-#pragma nounroll
-    for (int iter = 0; iter < max_iter; ++iter) {
-      double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0};
-      // the DPP read of a VGPR needs two wait states after a VALU write of it (the registers come
-      // straight from the LDS reads, but a copy could be scheduled in between): pin them here
-      if constexpr (NQ == 4) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]), "+v"(Wq[3]));
-      else if constexpr (NQ == 3) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]));
-      else if constexpr (NQ == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
-      else asm volatile("s_nop 1" : "+v"(Wq[0]));
-      dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
-      x = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in lanes 4c .. 4c+2 of
-      // this lane's quad: three quad_perm broadcasts (v_mov_b32 DPP pairs), no LDS round trip
-      const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused
-      const double cfx = quad_bcast<0>(xm), cfy = quad_bcast<1>(xm), cfz = quad_bcast<2>(xm);
-      // Every lane runs both updates, unmasked (a select per state variable per iteration otherwise).  A
-      // lane without a variable has x = mu_x = 0 and infinite bounds: it stays at zero.  Outside the
-      // contacts lcbar / lr / mulc are garbage that nothing reads: w, the exit test, the reported norms
-      // and the write-back all select on the lane's kind.
-      {
-        const double v = x + mux;
-        const double tt = min2(v, vub);   // std::min(x(i), ub(i))   constraint_utils.cpp:43
-        xbar = max2(tt, vlb);             // std::max(., lb(i))
-        xr = x - xbar;                    // :95
-        mux += xr;                        // :101
+      for (int j = 0; j < n; ++j) ws[j * kWave + lane] = Mrow[j];
+      ws[n * kWave + lane] = xc;
+      if (!a.warm_start && isvar) xs[vi] = x;
+      if (lane == 0) {
+        a.flags[inst] = flags;
+        a.factor_ticks[inst] = ticks;
+        if (a.phase_ticks) {
+          const size_t B = (size_t)a.batch;
+          a.phase_ticks[0 * B + inst] = ph_asm;
+          a.phase_ticks[1 * B + inst] = ticks;
+          a.phase_ticks[2 * B + inst] = ph_solve;
+          a.phase_ticks[3 * B + inst] = ph_p3;
+          a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
+          a.phase_ticks[6 * B + inst] = ph_asm;
+          a.phase_ticks[7 * B + inst] = t_begin;
+        }
       }
-      {
-        lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_i != 0);
-        lr = x - lcbar;                   // :96
-        mulc += lr;                       // :102
-      }
-      exchange_w();                       // for the next iteration (harmless after the last)
-      // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test
-      // is one ballot instead of two wave reductions; the norms themselves (:97-98) are only
-      // reported, and are reduced once after the loop.  An empty contact set has norm 0.
-      // (bitwise, not short-circuit: lane masks combined with scalar instructions, no branches)
-      const bool fail = ((var_i != 0) & !(fabs(xr) < eps_b)) | ((cone_i != 0) & !(fabs(lr) < eps_f));
-      if (__builtin_amdgcn_ballot_w64(fail) == 0) {
-        n_iter = iter;
-        break;
-      }
+      return;
     }
-    if (a.max_iter > 0) {
-      // :97-98  abs(max(maxCoeff, -minCoeff)) == max_i |r_i| of the last iteration executed
-      x_res_norm = wave_max(isvar ? fabs(xr) : 0.0);
-      lc_res_norm = wave_max(is_cone ? fabs(lr) : 0.0);
-    }
-    // duals are part of the warm-start state (fcc_qp.hpp:149-150)
-    if (isvar) mux_s[vi] = mux;
-    if (is_cone) mulc_s[vi - s0] = mulc;
+    // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------
+    const AdmmLane<SH> L(a, inst, lane);
+    admm_iterations<SH>(a, L, lane, vbuf, Mrow, xc, x, n_iter, x_res_norm, lc_res_norm);
     ph_p4 = wall_clock64() - t4;
   }
 
   // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back -----------------------------------------
-  lds_fence();
-  const double ffy = quad_bcast<1>(x), ffz = quad_bcast<2>(x);   // this quad's contact force
-  double bv = 0.0, cv = 0.0;
-  if (isvar) {
-    const double tt = min2(x, fresh(ubp)[vi]);
-    const double p = max2(tt, fresh(lbp)[vi]);
-    const double dd = x - p;
-    bv = dd * dd;                                        // constraint_utils.cpp:61-65
-  }
-  if (is_cone && ccomp == 0) {
-    const double fx = x, fy = ffy, fz = ffz;
-    const double v = sqrt(fx * fx + fy * fy) - fresh(mup)[cidx] * fz;
-    cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
-  }
-  bv = sqrt(wave_sum(bv));
-  cv = wave_sum(cv);
-
-  if (isvar) xs[vi] = x;
+  const AdmmLane<SH> L(a, inst, lane);
+  epilogue_writeback<SH>(a, L, inst, lane, x, n_iter, flags, x_res_norm, lc_res_norm);
   if (lane == 0) {
-    a.n_iter[inst] = n_iter;
-    a.flags[inst] = flags;
-    a.metrics[0 * (size_t)a.batch + inst] = x_res_norm;
-    a.metrics[1 * (size_t)a.batch + inst] = lc_res_norm;
-    a.metrics[2 * (size_t)a.batch + inst] = bv;
-    a.metrics[3 * (size_t)a.batch + inst] = cv;
     a.factor_ticks[inst] = ticks;
     if (a.phase_ticks) {
       const size_t B = (size_t)a.batch;
@@ -1335,6 +1411,41 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       a.phase_ticks[7 * B + inst] = t_begin;
 #endif
     }
+  }
+}
+
+// Second half of the two-launch form: P4 + P5 for one instance per wavefront from the rows of rho G that
+// fused_kernel<SH, TIN, true> left in the workspace.  The loop needs ~170 registers and 512 bytes of LDS, so
+// two or three of these waves share a SIMD (the whole-solve kernel holds its 512 registers from the first load
+// to the last store and runs this loop alone on its SIMD, at about half the fp64 issue rate two waves reach).
+// Instances that were handed to the COD pass (fb_list) are skipped; they are solved by the list launch.
+template <class SH, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(kWave, WAVES_PER_SIMD) void admm_kernel(const KernelArgs a) {
+  constexpr int n = SH::n;
+  __shared__ __attribute__((aligned(16))) double vraw[kWave];
+  lds_f64 *const vbuf = (lds_f64 *)vraw;
+  const int lane = threadIdx.x;
+  const int inst = block_instance(a);
+  if (inst < 0) return;
+  const long long t_begin = wall_clock64();
+  const int flags = a.flags[inst];
+  if (a.fb_list && (flags & kFlagPresolveNumerical)) return;
+  const AdmmLane<SH> L(a, inst, lane);
+  const double *ws = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
+  double Mrow[n];
+#pragma unroll
+  for (int j = 0; j < n; ++j) Mrow[j] = ws[j * kWave + lane];
+  const double xc = ws[n * kWave + lane];
+  double x = L.isvar ? L.xs[L.vi] : 0.0;
+  int n_iter = 0;
+  double x_res_norm = 0.0, lc_res_norm = 0.0;
+  admm_iterations<SH>(a, L, lane, vbuf, Mrow, xc, x, n_iter, x_res_norm, lc_res_norm);
+  epilogue_writeback<SH>(a, L, inst, lane, x, n_iter, flags, x_res_norm, lc_res_norm);
+  if (lane == 0 && a.phase_ticks) {
+    const size_t B = (size_t)a.batch;
+    const long long dt = wall_clock64() - t_begin;
+    a.phase_ticks[4 * B + inst] = dt;
+    a.phase_ticks[5 * B + inst] += dt;
   }
 }
 

@@ -1867,8 +1867,21 @@ __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void gene
     const int total = *a.inst_count;
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_count = 0;
     for (int li = blockIdx.x; li < total; li += gridDim.x) run(a.inst_list[li], true);
-  } else if ((int)blockIdx.x < a.batch) {
-    run((int)blockIdx.x, false);
+  } else {
+    // block -> instance map (fccqp_device.h)
+    int inst;
+    if constexpr (WAVES > 1) {
+      __shared__ int claimed;
+      if (wave == 0) {
+        const int c = block_instance(a);
+        if (lane == 0) claimed = c;
+      }
+      __syncthreads();
+      inst = claimed;
+    } else {
+      inst = block_instance(a);
+    }
+    if (inst >= 0) run(inst, false);
   }
 }
 

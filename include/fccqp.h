@@ -72,8 +72,16 @@ enum {
 enum {
   FCCQP_KERNEL_AUTO = 0,     /* specialised kernel when the shape has one, else generic          */
   FCCQP_KERNEL_GENERIC = 1,  /* any shape: LDS/global-resident KKT, triangular solves per iter   */
-  FCCQP_KERNEL_FUSED = 2     /* shape-specialised: panel LDL^T in LDS + one block solve for
-                                G = (K_rho^-1)[0:n,0:n], mat-vec ADMM iterations (walking shape)  */
+  FCCQP_KERNEL_FUSED = 2,    /* shape-specialised (fused_shapes.def), one wavefront per QP, one launch:
+                                K_rho = U^T D U by 16 x 16 register tiles on the fp64 matrix cores with
+                                the forward solve fused in, rho G as a Gram product, presolve from
+                                W = I - rho G, mat-vec ADMM iterations with DPP-fed FMAs               */
+  FCCQP_KERNEL_FUSED_SPLIT = 3 /* the same in two launches: everything up to the presolve at one wave
+                                per SIMD, then the ADMM iterations + epilogue at two waves per SIMD
+                                (rho G takes a round trip through a device workspace of 8 * 64 * (n + 1)
+                                bytes per instance).  Bit-identical results; measured 3-4 % faster at
+                                batch 4096 with 100 iterations, 8 % slower with the paper's 15: AUTO
+                                never picks it                                  */
 };
 
 /* reference: struct FCCQPOptions, src/fcc_qp.hpp:30-35 (same defaults) */

@@ -17,8 +17,9 @@ weak: every GPU gets its own 4096 instances, `value` counts all of them.
 
 Rank 0 prints ONE JSON line with the driver's fields plus
   "roofline":     algorithmic HBM bytes per launch / mean kernel time (HIP events on the launch
-                  stream) against the 8 TB/s HBM3E peak -- the contract figure; this path is
-                  latency/LDS-bound, not bandwidth-bound (see DESIGN.md), so the fraction is small;
+                  stream) against the 8 TB/s HBM3E peak -- the contract figure; this path is bound by the
+                  fp64 unit (matrix cores + DPP-fed vector FMAs) and instruction issue, not by bandwidth
+                  (DESIGN.md section 4), so the fraction is small;
   "cpu_baseline": the CPU restatement of the reference algorithm (oracle/, kind "port": the
                   reference itself needs Eigen, which is not in the image) on the host cores.
 """
@@ -49,8 +50,8 @@ def parse_args():
     ap.add_argument("--workload", default="W-sat", choices=["W-sat", "W-mix", "W-easy", "W-psd"])
     ap.add_argument("--shape", default="walking", choices=["walking", "large"],
                     help="walking = FCCQP(60,38,12,38), the metric's shape; large = FCCQP(114,60,24,66), "
-                         "BASELINE configs[3] (secondary: generic kernel, four waves per QP)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fused"])
+                         "BASELINE configs[3] (secondary: cooperative kernel, four waves per QP)")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fused", "fused_split", "coop"])
     ap.add_argument("--options", default="harness", choices=["harness", "paper"],
                     help="harness: fcc_qp_test.py:78-83 (headline); paper: fccqp.pdf Table 1 (max_iter=15, eps=1e-4)")
     ap.add_argument("--warm", action="store_true",
@@ -63,6 +64,9 @@ def parse_args():
                          "split over the GPUs, rank g taking [g B / G, (g + 1) B / G)  (SURVEY.md 8e)")
     ap.add_argument("--batch-global", type=int, default=BATCH_PER_GPU,
                     help="global batch for --scaling strong (4096 = the metric's batch; 65536 = BASELINE configs[4])")
+    ap.add_argument("--single-input-set", action="store_true",
+                    help="re-solve ONE resident batch every step (rounds 1-2 did; its inputs then partly sit in the "
+                         "Infinity Cache); default: alternate between two resident copies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -72,18 +76,59 @@ def parse_args():
 
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector fp64 (MI355X_MICROARCH.md)
+KERNEL_NAMES = {1: "generic", 2: "fused", 3: "fused_split", 4: "coop"}
 
 
-def fp64_diag(shape, warm, n_iter_mean, at_max_frac, nb, kernel_ms):
-    """Algorithmic flops of the reference algorithm per launch: f
-    factorisations of N^3/3, p presolve back-solves and K iterations of 2 N^2 each."""
+def fused_mfma_count(n, m):
+    """v_mfma_f64_16x16x4 instructions the one-wave fused kernel executes per QP: (K_rho factorisation + forward
+    solve, Gram product, factorisation of W) -- the loop bounds of tile_factor_forward / gram_output /
+    tile_factor_store in fcc_qp_amd/csrc/fccqp_fused_impl.h restated (walking shape: 468 + 196 + 64 = 728, the count
+    in the shipped code object)."""
+    N = n + m
+    border = N % 16 if (N % 16 != 0 and N - N % 16 >= n and (n % 16) + (N % 16) <= 15 and N % 16 <= 3) else 0
+    N1 = N - border
+    NRB, NCB, cbd, NW = (N1 + 15) // 16, 4, n // 16, (n + 15) // 16
+    zero_tile = lambda K, cb: K < cb and cb != cbd
+    kmin = lambda cb: 0 if cb == cbd else cb
+    f = g = w = 0
+    for P in range(NRB):
+        ks = sum(1 for r in range(4) if 16 * P + 4 * r < N1)
+        live = sum(1 for cb in range(NCB) if not zero_tile(P, cb))
+        f += ks * ((NRB - P - 1) + live)
+        for I in range(P + 1, NRB):
+            f += ks * ((NRB - I) + live)
+    for I in range(cbd + 1 if border else NW):
+        for K in range(NRB):
+            if K >= kmin(I):
+                ks = sum(1 for r in range(4) if 4 * (4 * K + r) < N1)
+                g += ks * sum(1 for J in range(I, cbd + 1) if K >= kmin(J))
+    for P in range(NW):
+        ks = sum(1 for r in range(4) if 16 * P + 4 * r < n)
+        w += ks * (NW - P - 1) + sum(4 * (NW - I) for I in range(P + 1, NW))
+    return f, g, w
+
+
+def fp64_diag(shape, warm, n_iter_mean, at_max_frac, nb, kernel_ms, fused=True):
+    """Two flop counts per launch against the 78.6 TFLOP/s vector-fp64 peak:
+    `frac`           the REFERENCE algorithm's flops: f factorisations of N^3/3, p presolve
+                     back-solves and K iterations of 2 N^2 each -- what a CPU running fcc_qp.cpp would execute;
+    `frac_executed`  what the fused kernel executes: its MFMAs (1024 FMAs each; one N^3/3-class factorisation with the
+                     forward solve of n + 1 right-hand sides fused in, the Gram product, and -- cold starts -- the
+                     n x n factorisation of W instead of a second N^3/3) plus the K mat-vecs of n DPP-fed wave FMAs."""
     N = shape.n + shape.m
     f, p = (1, 0) if warm else (2, 1)
     k_exec = n_iter_mean + (1.0 - at_max_frac)        # a converged instance executed n_iter + 1 iterations
     flops = nb * (f * N ** 3 / 3.0 + (p + k_exec) * 2.0 * N * N)
     ach = flops / (kernel_ms * 1e-3) / 1e12
-    return {"flops_per_launch": flops, "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / FP64_VECTOR_PEAK_TFLOPS}
+    out = {"flops_per_launch": flops, "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "counts": "reference algorithm (two N^3/3 on a cold start)"}
+    if fused and shape.n < 64:
+        mf, mg, mw = fused_mfma_count(shape.n, shape.m)
+        mfma = mf + mg + (0 if warm else mw)
+        ex = nb * (mfma * 2048.0 + k_exec * shape.n * 64 * 2.0)
+        out.update(flops_executed_per_launch=ex, mfma_per_solve=mfma, achieved_executed=ex / (kernel_ms * 1e-3) / 1e12,
+                   frac_executed=ex / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS)
+    return out
 
 
 def cpu_baseline(shape, options, batch_obj, log):
@@ -196,7 +241,7 @@ def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup
         mean_ms = float(np.mean(kms))
         rec = {"value": nb * steps / wall, "unit": "solves/s", "ms_per_step": 1e3 * wall / steps, "kernel_ms_mean": mean_ms,
                "roofline_frac": ab / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": ab,
-               "kernel": {1: "generic", 2: "fused"}[solver.kernel_in_use()], "parity": par,
+               "kernel": KERNEL_NAMES[solver.kernel_in_use()], "parity": par,
                "n_iter_mean": float(it.mean()), "n_iter_at_max_frac": float(np.mean(it == options["max_iter"])),
                "workload": f"{wl} FCCQP{tuple(shape.ctor_args)} {'warm' if warm else 'cold'} max_iter={options['max_iter']}"
                            f"{' fp32 storage' if f32 else ''}, {distinct} distinct instances tiled to {nb}"}
@@ -219,10 +264,80 @@ def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup
     run("f32_storage", P.WALKING, "W-sat", P.HARNESS_OPTIONS, f32=True)
     # the walking shape on the any-shape kernel
     run("generic_kernel", P.WALKING, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_GENERIC)
-    # BASELINE configs[3]: 36-DoF / 8-contact shape (generic kernel, four waves per QP)
+    # the two-launch form of the fused kernel (ADMM loop at two waves per SIMD): the measured A/B of DESIGN.md section 7
+    run("fused_split", P.WALKING, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_FUSED_SPLIT)
+    run("fused_split_w_mix", P.WALKING, "W-mix", P.HARNESS_OPTIONS, kernel=F.KERNEL_FUSED_SPLIT)
+    # BASELINE configs[3]: 36-DoF / 8-contact shape -- cooperative kernel (four waves per QP share the register
+    # tiles), and the generic kernel it replaced for this shape
     run("large_shape", P.LARGE, "W-sat", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
+    run("large_shape_generic", P.LARGE, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_GENERIC, distinct=32, parity_k=16, steps=4, warmup=1)
+    run("large_shape_w_mix", P.LARGE, "W-mix", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
+    out["batch_sweep"] = batch_sweep(F, P, torch, dev, dev_index, log)
+    out["single_instance"] = single_instance(F, P, log)
     out["end_to_end"] = end_to_end(P, O, dev_index, log)
     out["end_to_end_f32"] = end_to_end(P, O, dev_index, log, f32=True)
+    return out
+
+
+def batch_sweep(F, P, torch, dev, dev_index, log):
+    """solves/s and kernel time of the headline workload (W-sat, walking shape, harness options, cold) at the batch
+    sizes a reader needs to predict the multi-GPU curves from ONE GPU: 512 / 1024 / 2048 = the per-GPU share of the
+    metric's batch 4096 split over 8 / 4 / 2 GPUs (--scaling strong), 8192 = one GPU's shard of BASELINE
+    configs[4] (65536 over 8 GPUs) and 65536 = all of it on one GPU.  Inputs resident, 256 distinct instances tiled."""
+    import numpy as np
+    out = {}
+    base = P.workload("W-sat", 256, P.WALKING)
+    for nb in (512, 1024, 2048, 4096, 8192, 65536):
+        reps = -(-nb // 256)
+        tens = [torch.from_numpy(np.ascontiguousarray(a)).to(dev).repeat((reps,) + (1,) * (a.ndim - 1))[:nb].contiguous()
+                for a in base.arrays()]
+        solver = F.FCCQPBatch(*P.WALKING.ctor_args, nb, dev_index)
+        o = F.FCCQPOptions()
+        o.max_iter, o.rho, o.eps_fcone, o.eps_bound = (P.HARNESS_OPTIONS[k] for k in ("max_iter", "rho", "eps_fcone", "eps_bound"))
+        solver.set_options(o)
+        steps = 20 if nb <= 8192 else 5
+        wall, kms = _timed_steps(torch, lambda: F.solve_tensors(solver, *tens), steps, 2)
+        sol = solver.GetSolution()
+        z = np.asarray(sol.z)
+        tiled_ok = bool(np.array_equal(z[:256], z[256:512])) if nb >= 512 else None
+        out[str(nb)] = {"solves_per_s": nb * steps / wall, "kernel_ms_mean": float(np.mean(kms)), "ms_per_step": 1e3 * wall / steps,
+                        "us_per_wave_round": 1e3 * float(np.mean(kms)) / max(1.0, nb / 1024.0), "tiled_copies_bit_identical": tiled_ok}
+        log(f"[bench] batch_sweep {nb}: {out[str(nb)]['solves_per_s'] / 1e6:.3f} M solves/s, kernel {np.mean(kms):.3f} ms")
+        del solver, tens
+        torch.cuda.empty_cache()
+    # what the strong-scaling split of the metric's batch can reach: 4096 / G instances per GPU, G GPUs side by side
+    t1 = out["4096"]["kernel_ms_mean"]
+    out["predicted_strong_scaling_efficiency_batch4096"] = {
+        str(g): t1 / (g * out[str(4096 // g)]["kernel_ms_mean"]) for g in (2, 4, 8)}
+    return out
+
+
+def single_instance(F, P, log, length=60):
+    """One QP at a time through the reference's own class surface (FCCQP.Solve + GetSolution, host arrays in and
+    out: /root/reference/src/main.cpp:42-54, loop of /root/reference/fcc_qp_test.py:86-89): median wall microseconds
+    per call over a synthetic gait sequence, cold with the harness options and warm-started with the paper's."""
+    import numpy as np
+    out = {}
+    qps = P.gait_sequence(length, P.WALKING, seed0=5000)
+    for name, opts, warm in (("cold_harness", P.HARNESS_OPTIONS, False), ("warm_paper", P.PAPER_OPTIONS, True)):
+        s = F.FCCQP(*P.WALKING.ctor_args)
+        o = F.FCCQPOptions()
+        o.max_iter, o.rho, o.eps_fcone, o.eps_bound = (opts[k] for k in ("max_iter", "rho", "eps_fcone", "eps_bound"))
+        s.set_options(o)
+        w_solve, w_get, its, ktime = [], [], [], []
+        for i, qp in enumerate(qps):
+            s.set_warm_start(warm and i > 0)
+            t0 = time.perf_counter()
+            s.Solve(qp["Q"], qp["b"], qp["A_eq"], qp["b_eq"], qp["friction_coeffs"], qp["lb"], qp["ub"])
+            t1 = time.perf_counter()
+            r = s.GetSolution()
+            t2 = time.perf_counter()
+            w_solve.append(t1 - t0); w_get.append(t2 - t1); its.append(r.details.n_iter)
+        ws, wg = 1e6 * np.array(w_solve[5:]), 1e6 * np.array(w_get[5:])
+        out[name] = {"solve_us_median": float(np.median(ws)), "solve_us_p10": float(np.percentile(ws, 10)),
+                     "solve_us_p90": float(np.percentile(ws, 90)), "get_solution_us_median": float(np.median(wg)),
+                     "n_iter_mean": float(np.mean(its)), "calls": len(ws)}
+        log(f"[bench] single_instance {name}: Solve {np.median(ws):.0f} us + GetSolution {np.median(wg):.0f} us, mean n_iter {np.mean(its):.1f}")
     return out
 
 
@@ -349,16 +464,23 @@ def main():
                                                    options["eps_fcone"], options["eps_bound"])
     solver.set_options(o)
     solver.set_warm_start(False)
-    solver.set_kernel({"auto": F.KERNEL_AUTO, "generic": F.KERNEL_GENERIC, "fused": F.KERNEL_FUSED}[args.kernel])
+    solver.set_kernel({"auto": F.KERNEL_AUTO, "generic": F.KERNEL_GENERIC, "fused": F.KERNEL_FUSED,
+                       "fused_split": F.KERNEL_FUSED_SPLIT, "coop": F.KERNEL_COOP}[args.kernel])
     if args.inputs == "f32":   # the problem IS the float-rounded one: oracle and CPU baseline see the same values
         batch = P.Batch(*(a.astype(np.float32).astype(np.float64) for a in batch.arrays()))
     tens = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in batch.arrays()]   # resident in HBM
     if args.inputs == "f32":
         tens = [t.float() for t in tens]
+    # A second resident copy of the batch: the timed steps alternate between the two, so that a step's inputs are
+    # not what the previous step left in the 256 MiB Infinity Cache (one walking-shape batch of 4096 is 202 MB; two
+    # do not fit).  With a single resident set, PMC traffic read below the algorithmic bytes.
+    sets = [tens, [t.clone() for t in tens]] if not args.single_input_set else [tens]
     torch.cuda.synchronize()
+    step_no = [0]
 
     def step():
-        F.solve_tensors(solver, *tens)          # one launch on torch's current stream
+        F.solve_tensors(solver, *sets[step_no[0] % len(sets)])          # one launch on torch's current stream
+        step_no[0] += 1
 
     # ---- parity gate: a sample against the CPU oracle --------------------
     step()
@@ -434,8 +556,9 @@ def main():
                 "parallelism": f"batch-sharded x{world}, no collective",
                 # RCCL carries the two timing barriers and two scalar all-reduces (MAX of elapsed, SUM of solved)
                 "collective_bytes_per_run": 16 if world > 1 else 0,
-                "kernel": {1: "generic", 2: "fused"}[solver.kernel_in_use()], "input_storage": args.inputs,
+                "kernel": KERNEL_NAMES[solver.kernel_in_use()], "input_storage": args.inputs,
                 "n_iter_mean": float(n_iter.mean()), "n_iter_at_max_frac": float(np.mean(n_iter == options["max_iter"])),
+                "resident_input_sets": len(sets),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -444,7 +567,7 @@ def main():
             # diagnostic beside the contractual HBM roofline: algorithmic flops
             # F = f N^3/3 + (p + K) 2 N^2 per solve against the 78.6 TFLOP/s vector-fp64 peak
             "fp64": fp64_diag(shape, args.warm, float(n_iter.mean()), float(np.mean(n_iter == options["max_iter"])),
-                              nb, mean_ms),
+                              nb, mean_ms, fused=solver.kernel_in_use() in (2, 3)),
             "parity": parity,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -452,7 +575,7 @@ def main():
         if world == 1 and not args.no_extras and args.shape == "walking" and args.workload == "W-sat" \
                 and not args.warm and args.inputs == "f64" and args.options == "harness":
             from oracle import oracle as O
-            del tens
+            del tens, sets
             torch.cuda.empty_cache()
             try:
                 out.update(secondary_measurements(F, P, O, torch, dev, dev_index, log))

@@ -51,8 +51,9 @@ def hipcc() -> str:
 
 def build_lib(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip",
-                                            "fccqp_fused_f32.hip", "fccqp_fused_split.hip")]
+                                            "fccqp_fused_f32.hip", "fccqp_fused_split.hip", "fccqp_coop.hip")]
     deps = srcs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
+                          os.path.join(CSRC, "fccqp_coop_impl.h"), os.path.join(CSRC, "coop_shapes.def"),
                           os.path.join(CSRC, "fused_shapes.def"),
                           os.path.join(CSRC, "fccqp_cod_impl.h"),
                           os.path.join(ROOT, "include", "fccqp.h")]
@@ -66,13 +67,13 @@ def build_lib(force: bool = False) -> str:
                 # budget for `#pragma unroll`; left partly rolled it indexes register arrays dynamically
                 # fused kernel: loop headers on 256-byte boundaries -- its ADMM loop ran 5 % slower or faster
                 # with nothing but its placement in the code (the generic kernel, full of short loops, loses 2 %)
-                align = ["-falign-loops=256"] if "fused" in os.path.basename(src) else []
+                align = ["-falign-loops=256"] if ("fused" in os.path.basename(src) or "coop" in os.path.basename(src)) else []
                 _run([hipcc(), "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
                       "-fno-gpu-rdc", "-ffp-contract=off"] + align + ["-mllvm", "-pragma-unroll-threshold=400000",
                       "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-c", src, "-o", obj])
 
         # the translation units are independent
-        with ThreadPoolExecutor(max_workers=min(5, len(srcs))) as pool:
+        with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as pool:
             list(pool.map(compile_one, zip(srcs, objs)))
         _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
     return LIB

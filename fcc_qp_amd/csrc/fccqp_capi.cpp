@@ -30,6 +30,7 @@ struct fccqp_solver {
   bool last_was_f32 = false;   // the last solve read Q / A_eq as float
   double last_solve_wall = 0.0;
   size_t lds_limit = 64 * 1024;
+  int compute_units = 256;
   hipStream_t stream = nullptr;      // the solver's own stream
   hipStream_t last_stream = nullptr; // stream of the last enqueue
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;   // kernel start / end, async result copy
@@ -158,6 +159,16 @@ int ensure_vec_staging(fccqp_solver *s) {
   return FCCQP_OK;
 }
 
+// The handle's buffers (input staging, widened vectors, warm-start state, results, fallback list) are shared by
+// every solve on it.  Called by every solve entry point BEFORE its first write to any of them: work enqueued on
+// `stream` from here on runs after the previous solve's kernels (wherever they were enqueued) and after a result
+// copy that fccqp_get_z_async still has in flight on the solver's own stream.
+int order_after_previous(fccqp_solver *s, hipStream_t stream) {
+  if (s->solved && stream != s->last_stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev1, 0));
+  if (s->copy_pending && stream != s->stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev2, 0));
+  return FCCQP_OK;
+}
+
 int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *dA,
             const double *dbeq, const double *dmu, const double *dlb, const double *dub,
             hipStream_t stream, bool qa_f32 = false) {
@@ -178,21 +189,34 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   a.inst_list = nullptr; a.inst_count = nullptr; a.next_count = nullptr;
   a.cod_ws = s->dcod_ws; a.cod_stride = s->cod_stride;
 
-  const bool want_fused = s->kernel_request != FCCQP_KERNEL_GENERIC;
+  // kernel choice.  AUTO: the one-wave fused kernel where the shape has one, else the cooperative kernel, else the
+  // generic one.  (Where a shape has both specialised kernels -- the walking shape -- four waves per QP are no
+  // faster than one even when the chip is otherwise idle: 92.4 against 90.5 us cold with 100 iterations, 43.7
+  // against 47.3 us warm with the paper's 15, tools/coop_bench.py: the diagonal tiles, the barriers and the
+  // dependent chain of an ADMM iteration are serial either way.)
   const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s) && fccqp::fused_pointers_ok(a);
+  const bool can_coop = fccqp::coop_supported(s->n, s->m, s->nc, s->s);
+  int kernel = s->kernel_request;
+  if ((kernel == FCCQP_KERNEL_FUSED || kernel == FCCQP_KERNEL_FUSED_SPLIT) && !can_fuse)
+    return fail(s, FCCQP_ERR_UNSUPPORTED, "no fused kernel for this shape");
+  if (kernel == FCCQP_KERNEL_COOP && !can_coop)
+    return fail(s, FCCQP_ERR_UNSUPPORTED, "no cooperative kernel for this shape");
+  if (kernel == FCCQP_KERNEL_AUTO) {
+    if (can_fuse) kernel = FCCQP_KERNEL_FUSED;
+    else if (can_coop) kernel = FCCQP_KERNEL_COOP;
+    else kernel = FCCQP_KERNEL_GENERIC;
+  }
+  const bool want_fused = kernel == FCCQP_KERNEL_FUSED || kernel == FCCQP_KERNEL_FUSED_SPLIT;
 #ifdef FCCQP_TICKET_DISPATCH
   // tickets only where a launch runs in several rounds (all workgroups of a smaller one are resident at once:
   // 4 per CU of the fused kernel, at least 1 of the generic one)
-  const bool tickets = s->batch > ((want_fused && can_fuse) ? 1024 : 256);
+  const bool tickets = s->batch > (want_fused ? 1024 : 256);
   a.ticket = tickets ? s->dticket : nullptr;
   a.ticket_base = s->ticket_base;
 #endif
-  if ((s->kernel_request == FCCQP_KERNEL_FUSED || s->kernel_request == FCCQP_KERNEL_FUSED_SPLIT) && !can_fuse)
-    return fail(s, FCCQP_ERR_UNSUPPORTED,
-                "no fused kernel for this shape");
   // ADMM waves per SIMD of the two-launch form, 0: one launch
   int split = 0;
-  if (want_fused && can_fuse && s->kernel_request == FCCQP_KERNEL_FUSED_SPLIT) {
+  if (kernel == FCCQP_KERNEL_FUSED_SPLIT) {
     static const int waves = [] { const char *e = std::getenv("FCCQP_SPLIT_WAVES"); return (e && e[0] == '3') ? 3 : 2; }();
     if (!s->dsplit) {
       s->split_stride = fccqp::fused_split_workspace_doubles(s->n);
@@ -200,12 +224,13 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     }
     split = waves;
   }
-  // the handle's state (warm-start vectors, fallback list, counters, workspace) is shared by every
-  // solve: a solve enqueued on another stream than the previous one waits for it on the device
-  if (s->solved && stream != s->last_stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev1, 0));
+  // (ordering against the previous solve: order_after_previous, called by the entry points)
   HIP_TRY(s, hipEventRecord(s->ev0, stream));
   hipError_t e;
-  if (want_fused && can_fuse) {
+  if (kernel == FCCQP_KERNEL_COOP) {
+    s->kernel_used = FCCQP_KERNEL_COOP;
+    e = fccqp::launch_coop(a, stream, qa_f32);
+  } else if (want_fused) {
     s->kernel_used = split ? FCCQP_KERNEL_FUSED_SPLIT : FCCQP_KERNEL_FUSED;
     fccqp::KernelArgs af = a;
     if (split) { af.workspace = s->dsplit; af.workspace_stride = s->split_stride; }
@@ -320,6 +345,7 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
         (size_t)optin > lds)
       lds = (size_t)optin;                              // 160 KiB on gfx950
     s->lds_limit = lds;
+    s->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(s, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     HIP_TRY(s, hipEventCreate(&s->ev0));
     HIP_TRY(s, hipEventCreate(&s->ev1));
@@ -420,7 +446,7 @@ int fccqp_set_warm_start(fccqp_solver *s, int warm_start) {
   return FCCQP_OK;
 }
 int fccqp_set_kernel(fccqp_solver *s, int kernel) {
-  if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_FUSED_SPLIT) return FCCQP_ERR_INVALID_ARG;
+  if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_COOP) return FCCQP_ERR_INVALID_ARG;
   s->kernel_request = kernel;
   return FCCQP_OK;
 }
@@ -435,10 +461,12 @@ int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {
     *kernel_in_use = s->kernel_used;
     return FCCQP_OK;
   }
-  const bool fuse = s->kernel_request != FCCQP_KERNEL_GENERIC &&
-                    fccqp::fused_supported(s->n, s->m, s->nc, s->s);
-  *kernel_in_use = fuse ? (s->kernel_request == FCCQP_KERNEL_FUSED_SPLIT ? FCCQP_KERNEL_FUSED_SPLIT : FCCQP_KERNEL_FUSED)
-                        : FCCQP_KERNEL_GENERIC;
+  const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s), can_coop = fccqp::coop_supported(s->n, s->m, s->nc, s->s);
+  int k = s->kernel_request;
+  if (k == FCCQP_KERNEL_AUTO) {
+    k = can_fuse ? FCCQP_KERNEL_FUSED : (can_coop ? FCCQP_KERNEL_COOP : FCCQP_KERNEL_GENERIC);
+  }
+  *kernel_in_use = k;
   return FCCQP_OK;
 }
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc, int *lambda_c_start,
@@ -509,6 +537,8 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
   int rc = ensure_staging(s);
   if (rc != FCCQP_OK) return rc;
   hipStream_t st = s->stream;
+  rc = order_after_previous(s, st);
+  if (rc != FCCQP_OK) return rc;
   if (s->hin_block) {
     // small batch: gather into the page-locked mirror, one copy.  (The previous solve has finished reading
     // the mirror's device twin only when its kernel is done; the mirror itself is free once its copy is.)
@@ -573,6 +603,8 @@ int fccqp_solve_device(fccqp_solver *s, const double *dQ, const double *db, cons
   if (!g.ok) return fail(s, FCCQP_ERR_NO_DEVICE, "hipSetDevice failed");
   hipStream_t st = (stream == FCCQP_STREAM_OWN) ? s->stream : reinterpret_cast<hipStream_t>(stream);
   s->last_solve_wall = 0.0;
+  const int rc = order_after_previous(s, st);
+  if (rc != FCCQP_OK) return rc;
   return enqueue(s, dQ, db, dA_eq, db_eq, dfriction, dlb, dub, st);
 }
 
@@ -591,6 +623,8 @@ int fccqp_solve_async_f32(fccqp_solver *s, const float *Q, const float *b, const
   rc = ensure_vec_staging(s);
   if (rc != FCCQP_OK) return rc;
   hipStream_t st = s->stream;
+  rc = order_after_previous(s, st);
+  if (rc != FCCQP_OK) return rc;
   // Everything travels as float.  Q and A_eq land in the front halves of their f64 staging buffers and
   // are read there by the kernel; the five small vectors land in the unused back half of Q's buffer
   // (B n^2 floats: far more than B (3n + m + nc/3)) and are widened on the device.
@@ -622,6 +656,8 @@ int fccqp_solve_device_f32(fccqp_solver *s, const float *dQ, const float *db, co
   int rc = ensure_vec_staging(s);
   if (rc != FCCQP_OK) return rc;
   hipStream_t st = (stream == FCCQP_STREAM_OWN) ? s->stream : reinterpret_cast<hipStream_t>(stream);
+  rc = order_after_previous(s, st);          // the widened vectors are shared staging: before the first write
+  if (rc != FCCQP_OK) return rc;
   const float *const src[5] = {db, db_eq, dfriction, dlb, dub};
   double *const dst[5] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub};
   const size_t cnt[5] = {B * n, B * m, B * nm, B * n, B * n};
@@ -645,6 +681,8 @@ int fccqp_solve_f32(fccqp_solver *s, const float *Q, const float *b, const float
   int rc = ensure_staging(s);
   if (rc != FCCQP_OK) return rc;
   hipStream_t st = s->stream;
+  rc = order_after_previous(s, st);
+  if (rc != FCCQP_OK) return rc;
   // Q and A_eq travel and stay as float (in the front half of the f64 staging buffers); the small
   // vectors are widened here on the host
   HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));

@@ -1,0 +1,779 @@
+// fccqp_coop_impl.h -- shape-specialised gfx950 kernel: ONE WORKGROUP OF W WAVEFRONTS PER QP, the 16 x 16 register
+// tiles of fccqp_fused_impl.h shared out over the waves.  For the shapes the one-wave kernel cannot hold (num_vars
+// >= 64: BASELINE configs[3], FCCQP(114, 60, 24, 66), needs 126 live tiles = 1008 registers per lane) and for small
+// batches of the shapes it can (one QP then runs on four SIMDs instead of one).
+//
+// Hot path replaced (reference /root/reference): FCCQP::Solve src/fcc_qp.cpp:114-191, FCCQP::DoADMM :57-112,
+// projections src/constraint_utils.cpp:5-65, Eigen LDLT call sites fcc_qp.cpp:68,86,161,174.
+//
+// Same algebra, same elimination order and pivot rules as the one-wave kernel (read its header first):
+//   P0  K_rho from HBM straight into accumulator-layout tiles; tile COLUMN J of the upper triangle belongs to wave
+//       J mod W, right-hand-side tile column cb of [e_0 .. e_{n-1} | -b; b_eq] to wave cb mod W.  Every wave runs its
+//       own fully unrolled specialisation of the code (the kernel switches on the wave index once), so tile indices
+//       stay compile-time constants and a wave's tiles stay in its registers from the first load to the Gram product.
+//   P1  right-looking U^T D U by row panels.  Panel p: the owner of column p factorises the diagonal tile (tile_ldl)
+//       and publishes L^-1 and 1/d in LDS | barrier | every wave solves its own tiles of row p (V_pj = L^-1 C_pj,
+//       Y_p = L^-1 X_p) and publishes V_pj (2 KB per tile, stored and re-read lane for lane: register r of a tile IS
+//       the MFMA A operand of k-step r) | barrier | every wave updates its own columns,
+//       C_ij -= V_pi^T D^-1 V_pj, X_i -= V_pi^T D^-1 Y_p, with V_pi read from LDS.  Two barriers per panel, the
+//       published tiles double-buffered by panel parity.
+//   P3  Gram product G = Y^T D^-1 Y by row blocks K of Y: publish Y[K][.] | barrier | accumulate the own tile
+//       columns.  rho G goes through an n x n LDS image to the ADMM layout, W = I - rho G stays in registers.
+//   Pw  presolve x0 = W^-1 x_c (Woodbury, as in the one-wave kernel): W factorised by the same panel scheme, its
+//       factor written packed to LDS, the two triangular sweeps by wave 0 (two rows per lane for n > 64).
+//   P4  ADMM iterations.  Rows (variables) live in lanes, 64 per "row half" (RH = 1 or 2 halves), the columns of
+//       rho G are split over CS = W / RH waves per half: every wave holds a 64 x (n / CS) block of rho G in
+//       registers, forms its partial mat-vec with DPP-fed FMAs, the partial sums meet in LDS (barrier), and every
+//       wave of a half repeats the (cheap) projections for that half's rows, so only w crosses waves again
+//       (second barrier, not needed when RH == 1).
+//   P5  metrics and write-back.
+// Not bitwise equal to the one-wave kernel (the mat-vec sums its columns in another order); both are within 1e-12
+// of the oracle on the synthetic workloads.
+#pragma once
+#include "fccqp_fused_impl.h"
+
+namespace fccqp {
+namespace coop {
+using namespace fused;
+
+__device__ __forceinline__ void wg_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+using lds_i32 = __attribute__((address_space(3))) int;
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int N_VARS, int N_EQ, int NC, int LC_START, int WAVES>
+struct Shape {
+  static constexpr int n = N_VARS, m = N_EQ, nc = NC, s = LC_START, N = n + m, W = WAVES;
+  static constexpr int NRB = (N + 15) / 16;          // row / column blocks of K_rho (identity-padded to whole tiles)
+  static constexpr int NXB = (n + 16) / 16;          // column blocks of the right-hand sides [E | r]
+  static constexpr int cbd = n / 16;                 // the block that holds the dense column r = [-b; b_eq]
+  static constexpr int NW = (n + 15) / 16;           // row / column blocks of G and W
+  static constexpr int RH = (n + 63) / 64;           // row halves of the ADMM phase
+  static constexpr int CS = W / RH;                  // column splits of the mat-vec
+  static constexpr int kPos = 64 * RH;               // lane positions (one per variable, some unused)
+  static_assert(n >= 1 && n <= 128 && m >= 1, "two row halves at most");
+  static_assert(W == 2 || W == 4 || W == 8, "waves per workgroup");
+  static_assert(W % RH == 0 && CS >= 1 && CS <= NW, "every column split owns at least one 16-column block");
+  static_assert(nc % 3 == 0 && nc > 0 && s + nc <= n, "fcc_qp.cpp:32-33; shapes without contacts run on the generic kernel");
+  static constexpr int kContacts = nc / 3;
+  static_assert(4 * kContacts <= kPos, "one quad of lanes per contact");
+  using Reduced = Packed<n>;
+  static constexpr int ownC(int J) { return J % W; }
+  static constexpr int ownX(int cb) { return cb % W; }
+  // column split c of the mat-vec owns the 16-column blocks [qlo(c), qlo(c + 1))
+  static constexpr int qlo(int c) { return (NW * c) / CS; }
+  // position (row half * 64 + lane) -> variable: contact c in positions 4c .. 4c+2, the other variables in the
+  // fourth position of those quads, then behind the contacts, in increasing order; -1: no variable
+  __device__ static __forceinline__ int pos_variable(const int pos) {
+    const int q = pos >> 2, r = pos & 3;
+    const bool in_quad = q < kContacts;
+    const int k = in_quad ? q : pos - 3 * kContacts;
+    const int other = (k < s) ? k : k + nc;
+    return (in_quad && r < 3) ? s + 3 * q + r : ((k < n - nc) ? other : -1);
+  }
+  // ---- LDS carve (doubles) ----
+  static constexpr int kSblk = 0, kSinv = 256, kSrcp = 512;            // diagonal tile exchange (tile, L^-1, 1/d)
+  static constexpr int kRcp = 528;                                      // 1/d of every row of K_rho (16 NRB)
+  static constexpr int kRhs = kRcp + 16 * NRB;                          // [-b; b_eq]; later x_c, x0
+  static constexpr int kRhsLen = cmax(16 * NRB, kPos + 64);
+  static constexpr int kRed = kRhs + kRhsLen;                           // end-of-solve reductions [RH][4]
+  static constexpr int kInts = kRed + 4 * RH;                           // int words: flags
+  static constexpr int kBig = (kInts + 16 + 1) & ~1;
+  static constexpr int kTile = 256;                                     // doubles per published tile
+  static constexpr int kVbufLen = 2 * NRB * kTile;                      // V_pj of two panels
+  static constexpr int kYbufLen = 2 * NXB * kTile;                      // Y[K][.] of two row blocks
+  static constexpr int kImage = (n * n + 1) & ~1;                       // rho G, row-major
+  static constexpr int kWfac = (Reduced::kPacked + 1) & ~1;             // packed factor of W ...
+  static constexpr int kWfacLen = kWfac + 2 * NW * kTile;               // ... and the tiles its panels publish
+  // ADMM exchange: partial sums [2][CS][kPos] (by iteration parity), then w by variable (one copy, or one per wave when RH == 1), then the
+  // per-iteration exit words
+  static constexpr int kWv = 16 * NW + 16;                              // (+ a dummy slot for lanes without a variable)
+  static constexpr int kPart = 0, kWvOff = 2 * CS * kPos, kAdmmLen = kWvOff + ((RH == 1) ? W : 1) * kWv;
+  static constexpr int kBigLen = cmax(cmax(kVbufLen, kYbufLen), cmax(cmax(kImage, kWfacLen), kAdmmLen));
+  static constexpr int kLdsDoubles = kBig + kBigLen;
+  static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS of one CU");
+};
+
+// ---- P0: the own columns of the upper triangle of K_rho, from HBM into accumulator-layout tiles ----------------
+// (element map and clamping as issue_kkt_loads / convert_kkt_tiles of the one-wave kernel, without a border)
+template <class SH, int WV, class TIN>
+__device__ __forceinline__ void load_own_tiles(const TIN *__restrict__ Q, const TIN *__restrict__ A, const double rho,
+                                               const int lane, d4 (&C)[SH::NRB][SH::NRB]) {
+  constexpr int N = SH::N, n = SH::n, NRB = SH::NRB;
+  const int col = lane & 15, grp = lane >> 4;
+  TIN raw[NRB][NRB][4];
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+    if (16 * I < n) {
+#pragma unroll
+      for (int J = I; J < NRB; ++J) {
+        if (SH::ownC(J) == WV) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + grp + 4 * r, j = 16 * J + col;
+            const int lo = (I == J && j < i) ? j : i, hi = (I == J && j < i) ? i : j;
+            const int loc = (lo < n) ? lo : n - 1;
+            const int hic = (hi < N) ? hi : N - 1;
+            if (16 * J + 15 < n) {
+              raw[I][J][r] = Q[hic * n + loc];
+            } else if (16 * J >= n) {
+              raw[I][J][r] = A[(hic - n) * n + loc];
+            } else {
+              const TIN *src = (hic < n) ? Q + hic * n : A + (hic - n) * n;
+              raw[I][J][r] = src[loc];
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int I = 0; I < NRB; ++I) {
+#pragma unroll
+    for (int J = I; J < NRB; ++J) {
+      if (SH::ownC(J) == WV) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * I + grp + 4 * r, j = 16 * J + col;
+          const int lo = (I == J && j < i) ? j : i, hi = (I == J && j < i) ? i : j;
+          double v = (i == j && i >= N) ? 1.0 : 0.0;
+          if (16 * I < n) {
+            const double q = (double)raw[I][J][r] + ((I == J && i == j) ? rho : 0.0);
+            v = (lo < n && hi < N) ? q : v;
+          }
+          C[I][J][r] = v;
+        }
+      }
+    }
+  }
+}
+
+// publish / fetch one tile: register r of lane l at [256 t + 64 r + l]
+__device__ __forceinline__ void tile_publish(lds_f64 *buf, const int lane, const d4 &t) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) buf[64 * r + lane] = t[r];
+}
+__device__ __forceinline__ d4 tile_fetch(const lds_f64 *buf, const int lane) {
+  d4 t;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t[r] = buf[64 * r + lane];
+  return t;
+}
+
+// diagonal tile of a panel: the owner factorises it and leaves L^-1 (strictly lower part) and 1/d in the exchange area
+template <int kValid, bool WITH_INVERSE>
+__device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &Cpp, double (&T)[16], double &rmine, const double max_rcp) {
+  const int col = lane & 15, grp = lane >> 4;
+  lds_f64 *const Sblk = L + 0, *const Sinv = L + 256, *const Srcp = L + 512;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Sblk[16 * col + grp + 4 * r] = Cpp[r];
+  lds_fence();
+  double Y[16];
+  const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
+#pragma unroll
+  for (int ip = 0; ip < 8; ++ip) {
+    const d2 t = colp[ip];
+    T[2 * ip] = t.x;
+    T[2 * ip + 1] = t.y;
+  }
+  lds_fence();
+  const bool bad = tile_ldl<kValid, WITH_INVERSE>(T, Y, rmine, col, max_rcp);
+  if (lane < 16) {
+    if constexpr (WITH_INVERSE) {
+      lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
+#pragma unroll
+      for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
+    }
+    Srcp[col] = rmine;
+  }
+  return bad;
+}
+
+// ---- P1: K_rho = U^T D U with the forward solve of [E | r] fused in, tile columns shared out over the waves ----
+template <class SH, int WV>
+__device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, d4 (&C)[SH::NRB][SH::NRB],
+                                                    d4 (&X)[SH::NRB][SH::NXB]) {
+  constexpr int N = SH::N, n = SH::n, NRB = SH::NRB, NXB = SH::NXB, cbd = SH::cbd;
+  const int col = lane & 15, grp = lane >> 4;
+  lds_f64 *const Sinv = L + SH::kSinv, *const Srcp = L + SH::kSrcp, *const rhs = L + SH::kRhs;
+  lds_f64 *const Vbuf = L + SH::kBig;
+  lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
+  auto zero_tile = [](int K, int cb) { return K < cb && cb != cbd; };
+  auto kfirst = [](int cb) { return (cb == cbd) ? 0 : cb; };
+  auto x_initial = [&](const int I, const int cb) {
+    d4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * I + grp + 4 * r, c = 16 * cb + col;
+      double v = 0.0;
+      if (I == cb) v = (row == c && c < n) ? 1.0 : 0.0;
+      if (cb == cbd) v = (c == n) ? ((row < N) ? rhs[row < N ? row : 0] : 0.0) : v;
+      t[r] = v;
+    }
+    return t;
+  };
+  static_for<0, NRB>([&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    constexpr int kValid = (N - 16 * P < 16) ? N - 16 * P : 16;
+    // (1) diagonal tile, by its owner
+    if constexpr (SH::ownC(P) == WV) {
+      double T[16], rmine;
+      const bool bad = diag_tile<kValid, true>(L, lane, C[P][P], T, rmine, 0.0);
+      if (lane < 16) L[SH::kRcp + 16 * P + col] = rmine;
+      if (bad && lane == 0) iflags[0] = 1;
+    }
+    wg_barrier();
+    double Ainv[4], nrv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double li = Sinv[16 * (4 * r + grp) + col];
+      Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
+      nrv[r] = -Srcp[grp + 4 * r];
+    }
+    // (2) the own tiles of row panel P: V_pj = L^-1 C_pj (published), Y_p = L^-1 X_p
+#pragma unroll
+    for (int J = P + 1; J < NRB; ++J) {
+      if (SH::ownC(J) == WV) {
+        d4 t = C[P][J];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * P + 4 * r < N) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], C[P][J][r], t, 0, 0, 0);
+        C[P][J] = t;
+        tile_publish(Vbuf + ((P & 1) * NRB + J) * SH::kTile, lane, t);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NXB; ++cb) {
+      if (SH::ownX(cb) == WV && !zero_tile(P, cb)) {
+        if (P == kfirst(cb)) X[P][cb] = x_initial(P, cb);
+        d4 t = X[P][cb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * P + 4 * r < N) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], X[P][cb][r], t, 0, 0, 0);
+        X[P][cb] = t;
+      }
+    }
+    if constexpr (P + 1 < NRB) {
+      wg_barrier();
+      // (3) the rows below, own columns only; the A operand V_pi comes from the published tiles
+#pragma unroll
+      for (int I = P + 1; I < NRB; ++I) {
+#pragma unroll
+        for (int cb = 0; cb < NXB; ++cb)
+          if (SH::ownX(cb) == WV && !zero_tile(P, cb) && P == kfirst(cb)) X[I][cb] = x_initial(I, cb);
+        // does this wave touch row block I at all?
+        bool any = false;
+#pragma unroll
+        for (int J = I; J < NRB; ++J) any = any || (SH::ownC(J) == WV);
+#pragma unroll
+        for (int cb = 0; cb < NXB; ++cb) any = any || (SH::ownX(cb) == WV && !zero_tile(P, cb));
+        if (any) {
+          const d4 v = tile_fetch(Vbuf + ((P & 1) * NRB + I) * SH::kTile, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (16 * P + 4 * r < N) {
+              const double aop = v[r] * nrv[r];        // A[i][k] = -(V_pi[4r + k][i] / d_{4r + k})
+#pragma unroll
+              for (int J = I; J < NRB; ++J)
+                if (SH::ownC(J) == WV) C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
+#pragma unroll
+              for (int cb = 0; cb < NXB; ++cb)
+                if (SH::ownX(cb) == WV && !zero_tile(P, cb))
+                  X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[P][cb][r], X[I][cb], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  });
+}
+
+// ---- P3: rho G and x_c as the Gram product Y^T D^-1 Y; own tile columns J (the owner of X column J) ---------------
+// Leaves rho G in the LDS image (row-major n x n), x_c in xcv[0..n), and the own upper tiles of W = I - rho G in Wt.
+template <class SH, int WV>
+__device__ __forceinline__ void coop_gram(lds_f64 *L, const int lane, const double rho, const d4 (&X)[SH::NRB][SH::NXB],
+                                          d4 (&Wt)[SH::NW][SH::NW]) {
+  constexpr int N = SH::N, n = SH::n, NRB = SH::NRB, NXB = SH::NXB, NW = SH::NW, cbd = SH::cbd;
+  const int col = lane & 15, grp = lane >> 4;
+  lds_f64 *const Ybuf = L + SH::kBig, *const img = L + SH::kBig, *const xcv = L + SH::kRhs;
+  auto kmin = [](int cb) { return (cb == cbd) ? 0 : cb; };
+  constexpr int IMAX = NW - 1;                      // last row block of G that is needed
+  d4 Gt[NW][NXB];
+#pragma unroll
+  for (int J = 0; J <= cbd; ++J)
+    if (SH::ownX(J) == WV)
+#pragma unroll
+      for (int I = 0; I <= ((J < IMAX) ? J : IMAX); ++I) Gt[I][J] = d4{0.0, 0.0, 0.0, 0.0};
+  wg_barrier();      // the last panel's readers of the published V tiles are done: the buffer is reused
+  static_for<0, NRB>([&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    // publish the own non-zero tiles of row block K of Y
+#pragma unroll
+    for (int cb = 0; cb <= cbd; ++cb)
+      if (SH::ownX(cb) == WV && K >= kmin(cb)) tile_publish(Ybuf + ((K & 1) * NXB + cb) * SH::kTile, lane, X[K][cb]);
+    wg_barrier();
+    double rd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rd[r] = L[SH::kRcp + 16 * K + grp + 4 * r];
+#pragma unroll
+    for (int I = 0; I <= IMAX; ++I) {
+      if (K >= kmin(I)) {
+        bool any = false;
+#pragma unroll
+        for (int J = I; J <= cbd; ++J) any = any || (SH::ownX(J) == WV && K >= kmin(J));
+        if (any) {
+          const d4 y = tile_fetch(Ybuf + ((K & 1) * NXB + I) * SH::kTile, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (4 * (4 * K + r) < N) {
+              const double aop = y[r] * rd[r];
+#pragma unroll
+              for (int J = I; J <= cbd; ++J)
+                if (SH::ownX(J) == WV && K >= kmin(J))
+                  Gt[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[K][J][r], Gt[I][J], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  });
+  wg_barrier();      // every wave is done with the published Y tiles: the image goes over them
+#pragma unroll
+  for (int J = 0; J <= cbd; ++J) {
+    if (SH::ownX(J) == WV) {
+#pragma unroll
+      for (int I = 0; I <= ((J < IMAX) ? J : IMAX); ++I) {
+        const bool interior = (16 * I + 15 < n) && (16 * J + 15 < n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + grp + 4 * r, c = 16 * J + col;
+          const double gv = Gt[I][J][r];
+          const double g = rho * gv;
+          const bool inside = interior || (row < n && c < n);
+          if (inside) {
+            img[row * n + c] = g;
+            if (J != I) img[c * n + row] = g;
+          }
+          if (J == cbd && c == n && row < n) xcv[row] = gv;
+          if (J < NW) {
+            const double unit = (I == J && row == c) ? 1.0 : 0.0;
+            Wt[I][J][r] = inside ? unit - g : unit;
+          }
+        }
+      }
+    }
+  }
+  wg_barrier();
+}
+
+// ---- Pw: W = U^T D U (n x n) by the same panel scheme; the factor goes packed to LDS for the two sweeps ---------
+template <class SH, int WV>
+__device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, const double min_pivot, d4 (&C)[SH::NW][SH::NW]) {
+  using SW = typename SH::Reduced;
+  constexpr int n = SH::n, NW = SH::NW;
+  const int col = lane & 15, grp = lane >> 4;
+  lds_f64 *const M = L + SH::kBig;                          // packed factor
+  lds_f64 *const Vbuf = L + SH::kBig + SH::kWfac;
+  lds_f64 *const Sblk = L + SH::kSblk, *const Sinv = L + SH::kSinv, *const Srcp = L + SH::kSrcp;
+  lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
+  static_for<0, NW>([&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    constexpr int kValid = (n - 16 * P < 16) ? n - 16 * P : 16;
+    constexpr bool kLast = (P + 1 == NW);
+    if constexpr (SH::ownX(P) == WV) {
+      double T[16], rmine;
+      const bool bad = diag_tile<kValid, !kLast>(L, lane, C[P][P], T, rmine, 1.0 / min_pivot);
+      if (lane < 16 && col < kValid) {
+        const int jcol = 16 * P + col, cb = SW::cbase(jcol);
+        M[cb + jcol] = rmine;
+#pragma unroll
+        for (int i = 1; i < kValid; ++i) {
+          lds_f64 *dst = (i > col) ? M + cb + 16 * P + i : Sblk + col;      // (above the diagonal: a dummy slot)
+          *dst = -T[i];
+        }
+      }
+      if (bad && lane == 0) iflags[1] = 1;
+    }
+    if constexpr (!kLast) {
+      wg_barrier();
+      double Ainv[4], rv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double li = Sinv[16 * (4 * r + grp) + col];
+        Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
+        rv[r] = Srcp[grp + 4 * r];
+      }
+#pragma unroll
+      for (int J = P + 1; J < NW; ++J) {
+        if (SH::ownX(J) == WV) {
+          d4 t = C[P][J];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * P + 4 * r < n) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], C[P][J][r], t, 0, 0, 0);
+          C[P][J] = t;
+          tile_publish(Vbuf + ((P & 1) * NW + J) * SH::kTile, lane, t);
+          // L[16 J + col][16 P + row] = U_pj[row][col] = V_pj[row][col] / d_row
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int jrow = 16 * P + grp + 4 * r, irow = 16 * J + col;
+            if (16 * J + 15 < n || irow < n) M[SW::cbase(jrow) + irow] = t[r] * rv[r];
+          }
+        }
+      }
+      wg_barrier();
+#pragma unroll
+      for (int I = P + 1; I < NW; ++I) {
+        bool any = false;
+#pragma unroll
+        for (int J = I; J < NW; ++J) any = any || (SH::ownX(J) == WV);
+        if (any) {
+          const d4 v = tile_fetch(Vbuf + ((P & 1) * NW + I) * SH::kTile, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double aop = v[r] * -rv[r];
+#pragma unroll
+            for (int J = I; J < NW; ++J)
+              if (SH::ownX(J) == WV) C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
+          }
+        }
+      }
+    }
+  });
+  wg_barrier();
+}
+
+// x := (L D L^T)^-1 x, rows lane + 64 t (one wave, SLOTS rows per lane), M as left by coop_factor_store
+template <class SW, int SLOTS>
+__device__ __forceinline__ void solve_lds_slots(const lds_f64 *M, const int lane, double (&x)[SLOTS]) {
+  constexpr int N = SW::N;
+  static_assert(N <= 64 * SLOTS, "SLOTS rows per lane");
+  int rc[SLOTS], cbr[SLOTS];
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    rc[t] = (lane + 64 * t < N) ? lane + 64 * t : N - 1;
+    cbr[t] = SW::cbase(rc[t]);
+  }
+  // forward, unit lower: x_i -= L[i][k] x_k, i > k; L[i][k] = M[cbase(k) + i]
+#pragma unroll
+  for (int k = 0; k < N - 1; ++k) {
+    const double xk = bcast_lane(x[k / 64], k % 64);
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      if (64 * t + 63 > k) {
+        const double a = (lane + 64 * t > k && lane + 64 * t < N) ? M[SW::cbase(k) + rc[t]] : 0.0;
+        x[t] = fma(-a, xk, x[t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) x[t] *= M[cbr[t] + rc[t]];          // 1/d (pseudo-inverse rule folded in)
+  // backward with L^T: x_i -= L[k][i] x_k, i < k; L[k][i] = M[cbase(i) + k]: this lane's own columns
+#pragma unroll
+  for (int k = N - 1; k >= 1; --k) {
+    const double xk = bcast_lane(x[k / 64], k % 64);
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      if (64 * t < k) {
+        const double a = (lane + 64 * t < k) ? M[cbr[t] + k] : 0.0;
+        x[t] = fma(-a, xk, x[t]);
+      }
+    }
+  }
+}
+
+// ---- the whole solve as seen by wave WV of the workgroup ------------------------------------------------------
+template <class SH, int WV, class TIN>
+__device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, lds_f64 *L) {
+  constexpr int n = SH::n, m = SH::m, nc = SH::nc, s0 = SH::s, N = SH::N, NRB = SH::NRB, NW = SH::NW, RH = SH::RH, CS = SH::CS;
+  const int lane = threadIdx.x & 63;
+  lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
+  lds_f64 *const rhs = L + SH::kRhs;
+
+  const TIN *__restrict__ Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
+  const TIN *__restrict__ A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * m * n;
+  const double *__restrict__ bq = a.b + (size_t)inst * n;
+  const double *__restrict__ beq = a.b_eq + (size_t)inst * m;
+  const double *mup = a.mu + (size_t)inst * (nc / 3);
+  const double *lbp = a.lb + (size_t)inst * n;
+  const double *ubp = a.ub + (size_t)inst * n;
+  double *xs = a.x + (size_t)inst * n;
+  double *mux_s = a.mu_x + (size_t)inst * n;
+  double *mulc_s = a.mu_lc + (size_t)inst * nc;
+
+  // ADMM role of this wave: row half h, column split c
+  constexpr int h = WV % RH, c = WV / RH;
+  const int pos = 64 * h + lane;
+  const int var = SH::pos_variable(pos);
+  const bool isvar = var >= 0;
+  const int vi = isvar ? var : 0;
+  const bool is_cone = ((pos >> 2) < SH::kContacts) && ((pos & 3) < 3);
+  const int cidx = is_cone ? (pos >> 2) : 0;
+  const int ccomp = is_cone ? (pos & 3) : 0;
+
+  const long long t_begin = wall_clock64();
+  long long ticks = 0, ph_asm = 0, ph_p3 = 0, ph_solve = 0, ph_p4 = 0;
+  int flags = 0;
+
+  // [-b; b_eq] (fcc_qp.cpp:149-150) into LDS, by wave 0; flag words cleared
+  if constexpr (WV == 0) {
+#pragma unroll
+    for (int t = 0; t * 64 < 16 * NRB; ++t) {
+      const int i = lane + 64 * t;
+      if (i < 16 * NRB) {
+        double v = 0.0;
+        if (i < n) v = -bq[i];
+        else if (i < N) v = beq[i - n];
+        rhs[i] = v;
+      }
+    }
+    if (lane < 16) iflags[lane] = 0;
+  }
+
+  constexpr int q0 = SH::qlo(c), q1 = SH::qlo(c + 1);
+  constexpr int col0 = 16 * q0, ncol = ((16 * q1 < n) ? 16 * q1 : n) - col0, NQL = q1 - q0;
+  double Mrow[ncol];
+  double xc = 0.0, x = 0.0;
+  long long t4;
+  {
+    d4 Wt[NW][NW];
+    {
+      d4 C[NRB][NRB], X[NRB][SH::NXB];
+      load_own_tiles<SH, WV, TIN>(Q, A, a.rho, lane, C);
+      const long long t0 = wall_clock64();
+      ph_asm = t0 - t_begin;
+      wg_barrier();                                   // rhs and the cleared flags are visible
+      coop_factor_forward<SH, WV>(L, lane, C, X);
+      const long long t3 = wall_clock64();
+      ticks = t3 - t0;
+      coop_gram<SH, WV>(L, lane, a.rho, X, Wt);
+      t4 = wall_clock64();
+      ph_p3 = t4 - t3;
+    }
+    if (iflags[0]) flags |= kFlagAdmmNumerical;       // info() is not checked by the reference (cpp:68)
+    // this lane's row of rho G (columns of the own split) and its entry of x_c
+    {
+      const lds_f64 *img = L + SH::kBig;
+      xc = isvar ? rhs[vi] : 0.0;
+#pragma unroll
+      for (int j = 0; j < ncol; ++j) Mrow[j] = isvar ? img[vi * n + col0 + j] : 0.0;
+    }
+    if (a.warm_start) x = isvar ? xs[vi] : 0.0;       // fcc_qp.cpp:136-139
+    wg_barrier();                                     // the image is dead: the factor of W goes over it
+
+    // ---- presolve (fcc_qp.cpp:159-178; skipped on warm start): x0 = (I - rho G)^-1 x_c, see the one-wave kernel ----
+    if (!a.warm_start) {
+      flags |= kFlagPresolveRan;
+      const long long tw = wall_clock64();
+      coop_factor_store<SH, WV>(L, lane, kPresolveMinPivot, Wt);
+      ticks += wall_clock64() - tw;
+      const bool wbad = iflags[1] != 0;
+      if (wbad) {
+        flags |= kFlagPresolveNumerical;
+        if (a.fb_list) {
+          // hand the instance to the fallback pass (COD + generic kernel in list mode) and stop here
+          if (WV == 0 && lane == 0) {
+            a.fb_list[atomicAdd(a.fb_count, 1)] = inst;
+            a.flags[inst] = flags;
+          }
+          return;
+        }
+      }
+      if constexpr (WV == 0) {
+        using SW = typename SH::Reduced;
+        double r0[RH];
+#pragma unroll
+        for (int t = 0; t < RH; ++t) r0[t] = (lane + 64 * t < n) ? rhs[(lane + 64 * t < n) ? lane + 64 * t : 0] : 0.0;
+        solve_lds_slots<SW, RH>(L + SH::kBig, lane, r0);
+        lds_fence();
+        // x0 by variable index, over x_c (which every wave holds in registers by now)
+#pragma unroll
+        for (int t = 0; t < RH; ++t) rhs[lane + 64 * t] = r0[t];
+      }
+      wg_barrier();
+      x = isvar ? rhs[vi] : 0.0;
+      const long long t5 = wall_clock64();
+      ph_solve = t5 - t4;
+      t4 = t5;
+    }
+  }
+
+  // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------------------------------
+  lds_f64 *const part = L + SH::kBig + SH::kPart;
+  lds_f64 *const wv = L + SH::kBig + SH::kWvOff + ((RH == 1) ? WV : 0) * SH::kWv;
+  lds_i32 *const exitw = iflags + 4;                 // [2][RH]
+  const double vlb = isvar ? lbp[vi] : -HUGE_VAL;
+  const double vub = isvar ? ubp[vi] : HUGE_VAL;
+  const double vmu = is_cone ? mup[cidx] : 0.0;
+  double mux = 0.0, mulc = 0.0;
+  if (a.warm_start) {
+    mux = isvar ? mux_s[vi] : 0.0;
+    mulc = is_cone ? mulc_s[is_cone ? vi - s0 : 0] : 0.0;
+  }
+  double xbar = x, lcbar = x;                        // :74-75
+  double xr = 0.0, lr = 0.0;
+  const double vkc = cone_lane_constant(vmu, ccomp == 2);
+  const double eps_b = a.eps_bound, eps_f = a.eps_fcone;
+  lds_f64 *const wslot = wv + (isvar ? var : 16 * NW);
+  const int max_iter = a.max_iter;
+  int n_iter = max_iter;                             // :78
+  double Wq[NQL];
+  wg_barrier();                                      // everyone has x (and is done with the factor of W): the exchange area is free
+  auto publish_w = [&]() {
+    // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
+    const double w = is_cone ? (lcbar - mulc) : (xbar - mux);
+    if (RH == 1 || c == 0) *wslot = w;
+  };
+  auto fetch_w = [&]() {
+#pragma unroll
+    for (int q = 0; q < NQL; ++q) Wq[q] = wv[16 * (q0 + q) + (lane & 15)];
+  };
+  if (max_iter > 0) {
+    publish_w();
+    if constexpr (RH == 1) lds_fence(); else wg_barrier();
+    fetch_w();
+    lds_fence();
+  }
+#pragma nounroll
+  for (int iter = 0; iter < max_iter; ++iter) {
+    double acc[kMvAcc] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (NQL == 4) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]), "+v"(Wq[3]));
+    else if constexpr (NQL == 3) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]));
+    else if constexpr (NQL == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
+    else asm volatile("s_nop 1" : "+v"(Wq[0]));
+    dpp_matvec<0, ncol, NQL>(acc, Wq, Mrow);
+    if constexpr (CS > 1) {
+      // (double-buffered by iteration parity: a wave may write the next partial sums while a slower one still
+      // reads these; the barrier of the next iteration separates it from the one after)
+      lds_f64 *const pp = part + (iter & 1) * CS * SH::kPos;
+      pp[c * SH::kPos + pos] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      wg_barrier();
+      x = xc;
+#pragma unroll
+      for (int cc = 0; cc < CS; ++cc) x += pp[cc * SH::kPos + pos];
+    } else {
+      x = xc + ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    }
+    const double xm = x + mulc;
+    const double cfx = quad_bcast<0>(xm), cfy = quad_bcast<1>(xm), cfz = quad_bcast<2>(xm);
+    {
+      const double v = x + mux;
+      const double tt = min2(v, vub);   // constraint_utils.cpp:43
+      xbar = max2(tt, vlb);
+      xr = x - xbar;                    // :95
+      mux += xr;                        // :101
+    }
+    {
+      lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, ccomp == 2);
+      lr = x - lcbar;                   // :96
+      mulc += lr;                       // :102
+    }
+    publish_w();
+    // exit test :105-109 (see the one-wave kernel): one ballot per row half
+    const bool fail = (isvar & !(fabs(xr) < eps_b)) | (is_cone & !(fabs(lr) < eps_f));
+    const bool half_fails = __builtin_amdgcn_ballot_w64(fail) != 0;
+    bool any_fails = half_fails;
+    if constexpr (RH == 1) {
+      lds_fence();                                   // (w went to this wave's own copy)
+    } else {
+      if (c == 0 && lane == 0) exitw[(iter & 1) * RH + h] = half_fails ? 1 : 0;
+      wg_barrier();
+      any_fails = false;
+#pragma unroll
+      for (int hh = 0; hh < RH; ++hh) any_fails = any_fails || (exitw[(iter & 1) * RH + hh] != 0);
+    }
+    fetch_w();
+    lds_fence();
+    if (!any_fails) {
+      n_iter = iter;
+      break;
+    }
+  }
+  ph_p4 = wall_clock64() - t4;
+
+  // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back; one wave per row half reports ------------------------------
+  const double ffy = quad_bcast<1>(x), ffz = quad_bcast<2>(x);
+  double bv = 0.0, cv = 0.0;
+  if (isvar) {
+    const double tt = min2(x, vub);
+    const double p = max2(tt, vlb);
+    const double dd = x - p;
+    bv = dd * dd;                                        // constraint_utils.cpp:61-65
+  }
+  if (is_cone && ccomp == 0) {
+    const double v = sqrt(x * x + ffy * ffy) - vmu * ffz;
+    cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
+  }
+  bv = wave_sum(bv);
+  cv = wave_sum(cv);
+  double xrn = 0.0, lrn = 0.0;
+  if (max_iter > 0) {
+    xrn = wave_max(isvar ? fabs(xr) : 0.0);              // :97-98
+    lrn = wave_max(is_cone ? fabs(lr) : 0.0);
+  }
+  lds_f64 *const red = L + SH::kRed;
+  if (c == 0) {
+    if (isvar) {
+      xs[vi] = x;
+      mux_s[vi] = mux;                                   // duals are part of the warm-start state (fcc_qp.hpp:149-150)
+    }
+    if (is_cone) mulc_s[vi - s0] = mulc;
+    if (lane == 0) {
+      red[4 * h + 0] = xrn; red[4 * h + 1] = lrn; red[4 * h + 2] = bv; red[4 * h + 3] = cv;
+    }
+  }
+  wg_barrier();
+  if (WV == 0 && lane == 0) {
+    double r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+#pragma unroll
+    for (int hh = 1; hh < RH; ++hh) {
+      r0 = max2(r0, red[4 * hh + 0]); r1 = max2(r1, red[4 * hh + 1]);
+      r2 += red[4 * hh + 2]; r3 += red[4 * hh + 3];
+    }
+    a.n_iter[inst] = n_iter;
+    a.flags[inst] = flags;
+    a.metrics[0 * (size_t)a.batch + inst] = r0;
+    a.metrics[1 * (size_t)a.batch + inst] = r1;
+    a.metrics[2 * (size_t)a.batch + inst] = sqrt(r2);
+    a.metrics[3 * (size_t)a.batch + inst] = r3;
+    a.factor_ticks[inst] = ticks;
+    if (a.phase_ticks) {
+      const size_t B = (size_t)a.batch;
+      a.phase_ticks[0 * B + inst] = ph_asm;
+      a.phase_ticks[1 * B + inst] = ticks;
+      a.phase_ticks[2 * B + inst] = ph_solve;
+      a.phase_ticks[3 * B + inst] = ph_p3;
+      a.phase_ticks[4 * B + inst] = ph_p4;
+      a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
+      a.phase_ticks[6 * B + inst] = ph_asm;
+      a.phase_ticks[7 * B + inst] = t_begin;
+    }
+  }
+}
+
+template <class SH, class TIN>
+__global__ __launch_bounds__(kWave * SH::W) void coop_kernel(const KernelArgs a) {
+  __shared__ __attribute__((aligned(16))) double lds_raw[SH::kLdsDoubles];
+  lds_f64 *const L = (lds_f64 *)lds_raw;
+  const int inst = block_instance(a);
+  if (inst < 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  switch (wave) {
+    case 0: coop_wave<SH, 0, TIN>(a, inst, L); break;
+    case 1: coop_wave<SH, 1, TIN>(a, inst, L); break;
+    case 2: if constexpr (SH::W > 2) coop_wave<SH, 2, TIN>(a, inst, L); break;
+    case 3: if constexpr (SH::W > 2) coop_wave<SH, 3, TIN>(a, inst, L); break;
+    case 4: if constexpr (SH::W > 4) coop_wave<SH, 4, TIN>(a, inst, L); break;
+    case 5: if constexpr (SH::W > 4) coop_wave<SH, 5, TIN>(a, inst, L); break;
+    case 6: if constexpr (SH::W > 4) coop_wave<SH, 6, TIN>(a, inst, L); break;
+    case 7: if constexpr (SH::W > 4) coop_wave<SH, 7, TIN>(a, inst, L); break;
+    default: break;
+  }
+}
+
+}  // namespace coop
+}  // namespace fccqp

@@ -137,4 +137,9 @@ hipError_t launch_fused(const KernelArgs &a, hipStream_t stream, bool qa_f32, in
 long long fused_split_workspace_doubles(int n);
 hipError_t launch_fused_split(const KernelArgs &a, hipStream_t stream, bool qa_f32, int waves_per_simd);
 
+// ---- cooperative multi-wave kernel (fccqp_coop.hip) ----------------------------------------------
+bool coop_supported(int n, int m, int nc, int s);
+int coop_resident_workgroups(int n, int m, int nc, int s, int compute_units);
+hipError_t launch_coop(const KernelArgs &a, hipStream_t stream, bool qa_f32);
+
 }  // namespace fccqp

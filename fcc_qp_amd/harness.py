@@ -6,7 +6,7 @@ rho=5e-5, eps=1e-6/1e-6, max_iter=100 (:78-83) and shows eight matplotlib panels
 same loop produces a JSON-serialisable report with the same eight series (no interactive backend
 needed), and a second driver solves the whole log as ONE cold-start batch on the GPU -- the
 ``FCCQPBatch`` use case (the warm-start chain is sequential by construction and cannot be batched
-along the sequence without changing results; it can be batched across independent logs).
+along the sequence without changing results; it can be batched across independent logs: ``run_chains``).
 
     python -m fcc_qp_amd.harness [path/to/id_qp_log_walking.npz] [--out report.json] [--png plots.png]
 
@@ -86,6 +86,51 @@ def run_batch(qps: Sequence[Dict[str, np.ndarray]], shape: P.Shape = P.WALKING, 
     rep.update(mode="one cold-start batch", count=B.batch, wall_seconds=wall, options=options,
                kernel_ms=solver.LastKernelMilliseconds())
     return rep
+
+
+def run_chains(logs: Sequence[Sequence[Dict[str, np.ndarray]]], shape: P.Shape = P.WALKING, options: Dict = None,
+               device: int = 0) -> List[Dict]:
+    """K independent logs (robots, episodes) advanced in LOCK-STEP as one batch of K warm-started chains.
+
+    Every chain follows the reference loop (/root/reference/fcc_qp_test.py:86-89) --
+    ``set_warm_start(t > 0); Solve(qp_t); GetSolution()`` -- so chain k's results are those of ``run_sequence(logs[k])``;
+    the K solves of a time step are one kernel launch of ``FCCQPBatch(batch=K)``, whose warm-start state (x, mu_x,
+    mu_lambda_c per instance) stays resident on the device between steps.  This is the way to batch warm-started
+    solves: along ONE sequence they are sequential by construction.  Logs may have different lengths: a chain that
+    has ended keeps re-solving its last QP (its slot of the batch cannot be left out of a launch) and those results
+    are dropped.  Returns one report per log, each with the eight series of ``run_sequence``.
+    """
+    import fcc_qp_amd as F
+
+    options = dict(P.HARNESS_OPTIONS if options is None else options)
+    logs = [list(l) for l in logs]
+    if not logs or any(len(l) == 0 for l in logs):
+        raise ValueError("run_chains: every log needs at least one QP")
+    K, steps = len(logs), max(len(l) for l in logs)
+    solver = F.FCCQPBatch(*shape.ctor_args, K, device)
+    solver.set_options(_options(F, options))
+    zs = [[] for _ in range(K)]
+    details = [[] for _ in range(K)]
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for t in range(steps):
+        B = P.stack([l[min(t, len(l) - 1)] for l in logs])
+        solver.set_warm_start(t > 0)                                     # fcc_qp_test.py:87, for every chain
+        solver.Solve(*B.arrays())
+        sol = solver.GetSolution()
+        kernel_ms.append(solver.LastKernelMilliseconds())
+        for k, l in enumerate(logs):
+            if t < len(l):
+                zs[k].append(np.array(sol.z[k], copy=True))
+                details[k].append(sol[k].details)
+    wall = time.perf_counter() - t0
+    reports = []
+    for k, l in enumerate(logs):
+        rep = _series(np.vstack(zs[k]), details[k], shape)
+        rep.update(mode=f"warm-start chain {k} of {K} advanced in lock-step", count=len(l), wall_seconds=wall,
+                   options=options, kernel_ms_per_step=float(np.mean(kernel_ms)))
+        reports.append(rep)
+    return reports
 
 
 def save_png(report: Dict, path: str) -> bool:

@@ -76,12 +76,17 @@ enum {
                                 K_rho = U^T D U by 16 x 16 register tiles on the fp64 matrix cores with
                                 the forward solve fused in, rho G as a Gram product, presolve from
                                 W = I - rho G, mat-vec ADMM iterations with DPP-fed FMAs               */
-  FCCQP_KERNEL_FUSED_SPLIT = 3 /* the same in two launches: everything up to the presolve at one wave
+  FCCQP_KERNEL_FUSED_SPLIT = 3, /* the same in two launches: everything up to the presolve at one wave
                                 per SIMD, then the ADMM iterations + epilogue at two waves per SIMD
                                 (rho G takes a round trip through a device workspace of 8 * 64 * (n + 1)
                                 bytes per instance).  Bit-identical results; measured 3-4 % faster at
                                 batch 4096 with 100 iterations, 8 % slower with the paper's 15: AUTO
                                 never picks it                                  */
+  FCCQP_KERNEL_COOP = 4      /* shape-specialised (coop_shapes.def): one workgroup of 2-8 wavefronts per QP,
+                                the register tiles shared out over the waves.  Shapes with num_vars >= 64
+                                (BASELINE configs[3]: 2.3x the generic kernel).  AUTO: a listed shape that
+                                has no one-wave kernel (for the walking shape four waves per QP are no
+                                faster than one, even at batch 1)                                     */
 };
 
 /* reference: struct FCCQPOptions, src/fcc_qp.hpp:30-35 (same defaults) */
@@ -150,7 +155,11 @@ int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double 
  * (fccqp_host_register below, or hipHostMalloc) -- from pageable memory the HIP runtime copies
  * synchronously and nothing overlaps.  This is what lets a caller keep several handles in flight:
  * the H2D copy of one batch, the kernel of another and the D2H copy of a third overlap (bench.py's
- * `end_to_end` leg; SURVEY.md 8d timing protocol).  n_friction must equal nc/3 here. */
+ * `end_to_end` leg; SURVEY.md 8d timing protocol).  n_friction must equal nc/3 here.
+ * Small batches (staged inputs of at most 1 MiB, e.g. up to ~20 walking-shape instances) are gathered
+ * into one page-locked block inside the handle first: for those the call WAITS for the handle's
+ * previous kernel (it reads the block's device twin) before it returns, and the caller's arrays are
+ * free again as soon as it has. */
 int fccqp_solve_async(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
                       const double *b_eq, const double *friction_coeffs, int n_friction,
                       const double *lb, const double *ub);

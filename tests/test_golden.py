@@ -83,3 +83,11 @@ def test_hip_path_reproduces_golden(path, kernel):
         for key, mine in (("bounds_viol", d[0].bounds_viol), ("friction_cone_viol", d[0].friction_cone_viol)):
             ref = float(g["out_" + key][i])
             assert abs(mine - ref) <= 1e-6 * (1 + abs(ref)), key
+        # the reported ADMM residual norms (python: eps_bounds / eps_friction_cone, main.cpp:24-25) are those of
+        # the last iteration executed: comparable when both ran the same number of iterations.  They are
+        # differences of iterates, so the tolerance is relative to the iterate, like z's.
+        if d[0].n_iter == int(g["out_n_iter"][i]):
+            scale = 1 + np.max(np.abs(zr))
+            for key, mine in (("eps_bounds", d[0].admm_residual_bounds), ("eps_friction_cone", d[0].admm_residual_friction_cone)):
+                ref = float(g["out_" + key][i])
+                assert abs(mine - ref) <= Z_TOL * scale, (key, mine, ref)

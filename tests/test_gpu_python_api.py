@@ -178,6 +178,31 @@ def test_harness_reproduces_reference_loop_and_series(oracle, tmp_path):
     assert json.load(open(str(tmp_path / "r.json")))["sequence"]["count"] == 10
 
 
+def test_run_chains_equals_one_oracle_chain_per_log(oracle):
+    """harness.run_chains: K logs of different lengths advanced in lock-step as one warm-started batch; every
+    chain must reproduce the reference loop (/root/reference/fcc_qp_test.py:86-89) run on that log alone."""
+    from fcc_qp_amd import harness as H
+    lengths = [7, 4, 9, 1, 6]
+    logs = [P.gait_sequence(L, P.WALKING, seed0=8100 + 40 * k) for k, L in enumerate(lengths)]
+    reps = H.run_chains(logs, options=P.PAPER_OPTIONS)
+    assert [r["count"] for r in reps] == lengths
+    for k, (log, rep) in enumerate(zip(logs, reps)):
+        o = oracle.OracleFCCQP(60, 38, 12, 38)
+        op = oracle.FCCQPOptions(); op.__dict__.update(P.PAPER_OPTIONS); o.set_options(op)
+        for i, qp in enumerate(log):
+            o.set_warm_start(i > 0); o.Solve(**qp); s = o.GetSolution()
+            z = np.r_[rep["vdot"][i], rep["u"][i], rep["lambda_h"][i], rep["lambda_c"][i]]
+            assert np.max(np.abs(z - s.z[:50])) <= 1e-6 * (1 + np.max(np.abs(s.z))), (k, i)
+            assert abs(rep["n_iter"][i] - s.details.n_iter) <= 1
+            assert abs(rep["friction_cone_viol"][i] - s.details.friction_cone_viol) <= 1e-6 * (1 + abs(s.details.friction_cone_viol))
+            assert abs(rep["bounds_viol"][i] - s.details.bounds_viol) <= 1e-6 * (1 + abs(s.details.bounds_viol))
+        # ... and the one-chain driver on the same log
+        one = H.run_sequence(log, options=P.PAPER_OPTIONS)
+        assert np.array_equal(np.asarray(one["u"]), np.asarray(rep["u"])) and one["n_iter"] == rep["n_iter"]
+    with pytest.raises(ValueError):
+        H.run_chains([logs[0], []])
+
+
 # ---- zero-copy API: __dlpack__ in, tensors out, against the oracle (SURVEY.md 8(f)2) ----------------
 class _DLPackOnly:
     """A foreign device array: exports nothing but the DLPack protocol."""

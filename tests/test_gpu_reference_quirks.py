@@ -330,13 +330,30 @@ def test_low_rank_dense_cost_with_admm(oracle, dims):
     z0, _, d0, _ = gpu_solve(dims, opts0, B)
     assert rel_err(z0, x0).max() <= 1e-8, rel_err(z0, x0)
     z0_ref, _, _, _ = oracle.solve_batch(dims, opts0, *B.arrays(), nthreads=2)
-    sane = np.where(rel_err(z0_ref, x0) <= 1e-9)[0]
-    assert len(sane) >= 1
+    oracle_x0_err = rel_err(z0_ref, x0)
+    sane = np.where(oracle_x0_err <= 1e-9)[0]
+    dropped = np.where(oracle_x0_err > 1e-9)[0]
     opts = dict(max_iter=40, rho=1e-2, eps_fcone=1e-7, eps_bound=1e-7)
     z_ref, it_ref, det_ref, _ = oracle.solve_batch(dims, opts, *B.arrays(), nthreads=2)
     z, it, d, _ = gpu_solve(dims, opts, B)
     assert np.all(np.isfinite(z))
     assert_parity(z[sane], it[sane], z_ref[sane], it_ref[sane], tol=Z_TOL, what=f"low-rank cost {dims}")
+    # The deviation, as a recorded number instead of a silent filter: how many of the 8 instances are NOT compared
+    # with the oracle, how far the oracle's own presolve is from K^-1 r on them (the reason), and how far the HIP
+    # result is from the oracle's there.  (The oracle is an unpinned restatement: this documents a property of the
+    # restatement)  Pinned at the counts observed when the test was written.
+    far = rel_err(z[dropped], z_ref[dropped]) if len(dropped) else np.zeros(0)
+    print(f"low-rank cost {dims}: {len(dropped)} of {B.batch} instances not compared; oracle presolve error there "
+          f"{oracle_x0_err[dropped].tolist()}, HIP-vs-oracle distance there {far.tolist()}")
+    assert len(sane) >= 1, f"{len(dropped)} of {B.batch} instances dropped"
+    # observed (the oracle and the generator are deterministic): 0, 6 and 2 of 8 dropped, the oracle's x0 off by
+    # 0.07 .. 38 (relative) on them, and the HIP result within 6e-3 of the oracle's after 40 iterations all the same
+    assert len(dropped) == {(20, 14, 6, 10): 0, (12, 5, 6, 3): 6, (12, 8, 6, 3): 2}[dims]
+    assert far.size == 0 or far.max() <= 2e-2
+    # on every dropped instance the HIP presolve IS accurate (checked above for all 8 against LAPACK), so the
+    # distance to the oracle there is the oracle's own x0 error propagated through 40 iterations, not a HIP error
+    for j, i in enumerate(dropped):
+        assert rel_err(z0[i:i + 1], x0[i:i + 1])[0] <= 1e-8 and oracle_x0_err[i] > 1e-9
 
 
 # ---- (e) the flag is visible from Python ------------------------------------------------------------

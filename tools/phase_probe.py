@@ -1,0 +1,22 @@
+"""Device phase stamps of one kernel on one shape at one batch size:
+    python tools/phase_probe.py <walking|large> <coop|fused|generic|split> <batch> [W-sat] [max_iter]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from fcc_qp_amd import problems as P
+from tests import capi as C
+shape = {"walking": P.WALKING, "large": P.LARGE}[sys.argv[1]]
+kern = {"coop": C.KERNEL_COOP, "fused": C.KERNEL_FUSED, "generic": C.KERNEL_GENERIC, "split": C.KERNEL_FUSED_SPLIT}[sys.argv[2]]
+nb = int(sys.argv[3])
+wl = sys.argv[4] if len(sys.argv) > 4 else "W-sat"
+opts = dict(P.HARNESS_OPTIONS)
+if len(sys.argv) > 5:
+    opts["max_iter"] = int(sys.argv[5])
+B = P.workload(wl, nb, shape, distinct=min(nb, 32))
+s = C.Solver(*shape.ctor_args, batch=nb); s.set_kernel(kern); s.set_options(**opts)
+s.phase_seconds()
+ms = []
+for _ in range(6):
+    s.solve_ok(*B.arrays()); ms.append(s.kernel_ms())
+print(sys.argv[1:], "kernel us %.1f" % (1e3 * np.median(ms[1:])), "phases us [load, factor, presolve, gram, admm, total]:",
+      ["%.1f" % (1e6 * v) for v in s.phase_seconds()[:6]], flush=True)

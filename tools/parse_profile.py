@@ -48,7 +48,7 @@ for k in fetch:
     }
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 main = max(summary["kernels"].items(), key=lambda kv: kv[1]["hbm_bytes_per_launch_corrected"])
-kernel_id = 2 if "fused" in main[0] else 1
+kernel_id = 2 if "fused" in main[0] else (4 if "coop" in main[0] else 1)
 shape = "large" if "large" in tag else "walking"
 path = os.path.join(dst, "hbm_traffic.json")
 try:

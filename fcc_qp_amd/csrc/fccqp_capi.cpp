@@ -47,6 +47,20 @@ struct fccqp_solver {
   size_t in_off[7] = {0, 0, 0, 0, 0, 0, 0}, in_bytes = 0;
   // Likewise the per-instance results (z, metrics, ticks, n_iter, flags): one device block, one D2H copy.
   char *dres_block = nullptr, *hres_block = nullptr;
+  // small synchronous host-pointer solves (the reference's one-QP-at-a-time use): the kernel reads its inputs straight
+  // out of the page-locked block (hin_dev: the block's device-side address; no H2D copy), the result block is copied
+  // back behind the kernel under the same synchronisation (hres_fresh: GetSolution then copies nothing), and the
+  // fallback-list launch is issued only if an instance was flagged (pending_fb)
+  char *hin_dev = nullptr;
+  bool hres_fresh = false;
+  // the last solve was waited for on the host and recorded no events (a timing event costs ~5 us of stream time
+  // each; a one-QP solve is 50-90 us): nothing is left to wait for, and fccqp_last_kernel_ms reports host_device_ms,
+  // the host-measured time from the launch to the completion of the device work
+  bool quiesced = false;
+  float host_device_ms = 0.f;
+  bool fb_deferred = false;
+  fccqp::KernelArgs pending_fb{};
+  bool pending_fb_f32 = false;
   size_t res_off[5] = {0, 0, 0, 0, 0}, res_bytes = 0;
   // state / outputs
   double *dx = nullptr, *dmux = nullptr, *dmulc = nullptr, *dmetrics = nullptr, *dwork = nullptr;
@@ -143,6 +157,10 @@ int ensure_staging(fccqp_solver *s) {
   if (off <= kPinnedMirrorBytes) {
     // (failure to page-lock is not an error: the solve falls back to the seven separate copies)
     if (hipHostMalloc(reinterpret_cast<void **>(&s->hin_block), off, hipHostMallocDefault) != hipSuccess) s->hin_block = nullptr;
+    void *dev_alias = nullptr;
+    if (s->hin_block && hipHostGetDevicePointer(&dev_alias, s->hin_block, 0) == hipSuccess) s->hin_dev = static_cast<char *>(dev_alias);
+    else s->hin_dev = nullptr;
+    (void)hipGetLastError();
   }
   return FCCQP_OK;
 }
@@ -159,19 +177,27 @@ int ensure_vec_staging(fccqp_solver *s) {
   return FCCQP_OK;
 }
 
+// host wait for the last solve of the handle
+hipError_t wait_last(fccqp_solver *s) {
+  return (s->solved && !s->quiesced) ? hipEventSynchronize(s->ev1) : hipSuccess;
+}
+
 // The handle's buffers (input staging, widened vectors, warm-start state, results, fallback list) are shared by
 // every solve on it.  Called by every solve entry point BEFORE its first write to any of them: work enqueued on
 // `stream` from here on runs after the previous solve's kernels (wherever they were enqueued) and after a result
 // copy that fccqp_get_z_async still has in flight on the solver's own stream.
 int order_after_previous(fccqp_solver *s, hipStream_t stream) {
-  if (s->solved && stream != s->last_stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev1, 0));
+  if (s->solved && !s->quiesced && stream != s->last_stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev1, 0));
   if (s->copy_pending && stream != s->stream) HIP_TRY(s, hipStreamWaitEvent(stream, s->ev2, 0));
   return FCCQP_OK;
 }
 
 int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *dA,
             const double *dbeq, const double *dmu, const double *dlb, const double *dub,
-            hipStream_t stream, bool qa_f32 = false) {
+            hipStream_t stream, bool qa_f32 = false, bool defer_fallback = false) {
+  s->hres_fresh = false;
+  s->fb_deferred = false;
+  s->quiesced = false;
   fccqp::KernelArgs a{};
   a.n = s->n; a.m = s->m; a.nc = s->nc; a.s = s->s; a.batch = s->batch;
   a.warm_start = s->warm_start ? 1 : 0;
@@ -225,7 +251,8 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     split = waves;
   }
   // (ordering against the previous solve: order_after_previous, called by the entry points)
-  HIP_TRY(s, hipEventRecord(s->ev0, stream));
+  // (defer_fallback is the synchronous small-batch path: its caller waits on the host and records no events)
+  if (!defer_fallback) HIP_TRY(s, hipEventRecord(s->ev0, stream));
   hipError_t e;
   if (kernel == FCCQP_KERNEL_COOP) {
     s->kernel_used = FCCQP_KERNEL_COOP;
@@ -267,20 +294,51 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     b.ticket = nullptr;
 #endif
     b.inst_list = s->dfb_list; b.inst_count = cnt; b.next_count = cnt_next;
-    e = fccqp::launch_generic_list(b, s->lds_limit, blocks, stream, qa_f32);
+    if (defer_fallback) {
+      // the caller looks at the flags first (run_deferred_fallback): with nothing appended the counter is still zero
+      // and the pair of counters needs no turn
+      s->pending_fb = b; s->pending_fb_f32 = qa_f32; s->fb_deferred = true;
+      e = hipSuccess;
+    } else {
+      e = fccqp::launch_generic_list(b, s->lds_limit, blocks, stream, qa_f32);
+    }
     if (e != hipSuccess) {
       // the main kernel may have appended to `cnt`, and nothing will consume it: start the next
       // solve from a clean pair of counters
       (void)hipMemsetAsync(s->dfb_count, 0, 2 * sizeof(int), stream);
       return fail(s, FCCQP_ERR_HIP, "fallback kernel launch", e);
     }
-    s->solve_seq++;
+    if (!defer_fallback) s->solve_seq++;
   }
-  HIP_TRY(s, hipEventRecord(s->ev1, stream));
+  if (!defer_fallback) HIP_TRY(s, hipEventRecord(s->ev1, stream));
   s->last_stream = stream;
   s->last_was_warm = s->warm_start;
   s->last_was_f32 = qa_f32;
   s->solved = true;
+  return FCCQP_OK;
+}
+
+// Host wait for a short solve: poll the stream instead of sleeping on its completion signal (the blocking wait
+// costs a wake-up of 10-20 us, a fifth of a one-QP solve); falls back to the blocking wait after ~2 ms.
+hipError_t spin_synchronize(hipStream_t stream) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(stream);
+    if (q != hipErrorNotReady) return q;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(stream);
+  }
+}
+
+// the fallback-list launch that enqueue(.., defer_fallback = true) left out
+int run_deferred_fallback(fccqp_solver *s, hipStream_t stream) {
+  if (!s->fb_deferred) return FCCQP_OK;
+  s->fb_deferred = false;
+  hipError_t e = fccqp::launch_generic_list(s->pending_fb, s->lds_limit, s->fb_blocks, stream, s->pending_fb_f32);
+  if (e != hipSuccess) {
+    (void)hipMemsetAsync(s->dfb_count, 0, 2 * sizeof(int), stream);
+    return fail(s, FCCQP_ERR_HIP, "fallback kernel launch", e);
+  }
+  s->solve_seq++;
   return FCCQP_OK;
 }
 
@@ -514,7 +572,7 @@ int fccqp_get_z_async(fccqp_solver *s, double *z_pinned) {
   if (!s->solved) return fail(s, FCCQP_ERR_NOT_SOLVED, "GetSolution before Solve");
   DeviceGuard g(s->device);
   // behind the last solve, wherever it was enqueued
-  if (s->last_stream != s->stream) HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev1, 0));
+  if (!s->quiesced && s->last_stream != s->stream) HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev1, 0));
   HIP_TRY(s, hipMemcpyAsync(z_pinned, s->dx, sizeof(double) * (size_t)s->batch * (size_t)s->n,
                             hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipEventRecord(s->ev2, s->stream));
@@ -542,7 +600,7 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
   if (s->hin_block) {
     // small batch: gather into the page-locked mirror, one copy.  (The previous solve has finished reading
     // the mirror's device twin only when its kernel is done; the mirror itself is free once its copy is.)
-    if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+    HIP_TRY(s, wait_last(s));
     char *h = s->hin_block;
     std::memcpy(h + s->in_off[0], Q, sizeof(double) * B * n * n);
     std::memcpy(h + s->in_off[1], b, sizeof(double) * B * n);
@@ -552,14 +610,43 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
       std::memcpy(h + s->in_off[4] + sizeof(double) * nm * i, friction_coeffs + (size_t)n_friction * i, sizeof(double) * nm);
     std::memcpy(h + s->in_off[5], lb, sizeof(double) * B * n);
     std::memcpy(h + s->in_off[6], ub, sizeof(double) * B * n);
-    HIP_TRY(s, hipMemcpyAsync(s->din_block, h, s->in_bytes, hipMemcpyHostToDevice, st));
-    rc = enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st);
+    // The kernel reads the page-locked block in place (its device-side address): no H2D copy in front of it.
+    const char *src = s->hin_dev;
+    if (!src) {
+      HIP_TRY(s, hipMemcpyAsync(s->din_block, h, s->in_bytes, hipMemcpyHostToDevice, st));
+      src = s->din_block;
+    }
+    auto at = [&](int i) { return reinterpret_cast<const double *>(src + s->in_off[i]); };
+    const bool defer = wait && s->hres_block != nullptr;      // flags come back with the results: look before launching the list pass
+    const auto t_launch = std::chrono::high_resolution_clock::now();
+    rc = enqueue(s, at(0), at(1), at(2), at(3), at(4), at(5), at(6), st, /*qa_f32=*/false, defer);
     if (rc != FCCQP_OK) return rc;
     if (!wait) {
       s->last_solve_wall = 0.0;
       return FCCQP_OK;
     }
-    HIP_TRY(s, hipStreamSynchronize(st));
+    if (defer) {
+      // results behind the kernel, one synchronisation for both; GetSolution then copies nothing
+      HIP_TRY(s, hipMemcpyAsync(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost, st));
+      HIP_TRY(s, spin_synchronize(st));
+      bool flagged = false;
+      if (s->fb_deferred) {
+        const int *fl = reinterpret_cast<const int *>(s->hres_block + s->res_off[4]);
+        for (size_t i = 0; i < B; ++i) flagged = flagged || ((fl[i] & FCCQP_FLAG_PRESOLVE_NUMERICAL) != 0);
+      }
+      if (flagged) {          // rare: the COD pass, then the results again
+        rc = run_deferred_fallback(s, st);
+        if (rc != FCCQP_OK) return rc;
+        HIP_TRY(s, hipMemcpyAsync(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(s, hipStreamSynchronize(st));
+      }
+      s->fb_deferred = false;
+      s->hres_fresh = true;
+      s->quiesced = true;
+      s->host_device_ms = std::chrono::duration<float, std::milli>(std::chrono::high_resolution_clock::now() - t_launch).count();
+    } else {
+      HIP_TRY(s, hipStreamSynchronize(st));
+    }
     const auto t1s = std::chrono::high_resolution_clock::now();
     s->last_solve_wall = std::chrono::duration<double>(t1s - t0).count();  // src/fcc_qp.cpp:188-190
     return FCCQP_OK;
@@ -707,7 +794,7 @@ int fccqp_solve_f32(fccqp_solver *s, const float *Q, const float *b, const float
 int fccqp_synchronize(fccqp_solver *s) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   DeviceGuard g(s->device);
-  if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, wait_last(s));
   if (s->copy_pending) {
     HIP_TRY(s, hipEventSynchronize(s->ev2));
     s->copy_pending = false;
@@ -719,11 +806,11 @@ int fccqp_get_solution(fccqp_solver *s, double *z, fccqp_details *details) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   if (!s->solved) return fail(s, FCCQP_ERR_NOT_SOLVED, "GetSolution before Solve");
   DeviceGuard g(s->device);
-  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, wait_last(s));
   const size_t B = (size_t)s->batch, n = (size_t)s->n;
   const bool one_copy = s->hres_block != nullptr;
   if (one_copy) {   // small batch: the whole result block in one copy into page-locked memory
-    HIP_TRY(s, hipMemcpy(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost));
+    if (!s->hres_fresh) HIP_TRY(s, hipMemcpy(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost));
     if (z && n) std::memcpy(z, s->hres_block + s->res_off[0], sizeof(double) * B * n);
   } else if (z && n) {
     HIP_TRY(s, hipMemcpy(z, s->dx, sizeof(double) * B * n, hipMemcpyDeviceToHost));
@@ -781,7 +868,7 @@ int fccqp_get_solution_device(fccqp_solver *s, const double **z, const int **n_i
 int fccqp_get_state(fccqp_solver *s, double *x, double *mu_x, double *mu_lambda_c) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   DeviceGuard g(s->device);
-  if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, wait_last(s));
   const size_t B = (size_t)s->batch, n = (size_t)s->n, nc = (size_t)s->nc;
   if (x && n) HIP_TRY(s, hipMemcpy(x, s->dx, sizeof(double) * B * n, hipMemcpyDeviceToHost));
   if (mu_x && n) HIP_TRY(s, hipMemcpy(mu_x, s->dmux, sizeof(double) * B * n, hipMemcpyDeviceToHost));
@@ -793,7 +880,8 @@ int fccqp_get_state(fccqp_solver *s, double *x, double *mu_x, double *mu_lambda_
 int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x, const double *mu_lambda_c) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   DeviceGuard g(s->device);
-  if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, wait_last(s));
+  s->hres_fresh = false;               // x doubles as z: the page-locked copy of the results is stale now
   const size_t B = (size_t)s->batch, n = (size_t)s->n, nc = (size_t)s->nc;
   if (x && n) HIP_TRY(s, hipMemcpy(s->dx, x, sizeof(double) * B * n, hipMemcpyHostToDevice));
   if (mu_x && n) HIP_TRY(s, hipMemcpy(s->dmux, mu_x, sizeof(double) * B * n, hipMemcpyHostToDevice));
@@ -806,6 +894,10 @@ int fccqp_last_kernel_ms(fccqp_solver *s, float *ms) {
   if (!s || !ms) return FCCQP_ERR_INVALID_ARG;
   if (!s->solved) return fail(s, FCCQP_ERR_NOT_SOLVED, "no solve has been run");
   DeviceGuard g(s->device);
+  if (s->quiesced) {       // low-latency path: no events were recorded (see fccqp_solver::quiesced)
+    *ms = s->host_device_ms;
+    return FCCQP_OK;
+  }
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
   return FCCQP_OK;
@@ -817,13 +909,13 @@ int fccqp_phase_seconds(fccqp_solver *s, double out[8]) {
   DeviceGuard g(s->device);
   const size_t B = (size_t)s->batch;
   if (!s->dphase) {
-    if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+    HIP_TRY(s, wait_last(s));
     HIP_TRY(s, dmalloc(&s->dphase, 8 * B));
     HIP_TRY(s, hipMemset(s->dphase, 0, sizeof(long long) * 8 * B));
     return FCCQP_OK;
   }
   if (!s->solved) return FCCQP_OK;
-  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, wait_last(s));
   std::vector<long long> h(8 * B);
   HIP_TRY(s, hipMemcpy(h.data(), s->dphase, sizeof(long long) * 8 * B, hipMemcpyDeviceToHost));
   for (int p = 0; p < 8; ++p) {
@@ -839,7 +931,7 @@ int fccqp_debug_phase_ticks(fccqp_solver *s, long long *out, long long count) {
   DeviceGuard g(s->device);
   const long long have = s->dphase ? 8ll * s->batch : 0;
   if (!s->solved || count > have) return FCCQP_ERR_INVALID_ARG;
-  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, wait_last(s));
   HIP_TRY(s, hipMemcpy(out, s->dphase, sizeof(long long) * (size_t)count, hipMemcpyDeviceToHost));
   return FCCQP_OK;
 }
@@ -847,7 +939,7 @@ int fccqp_debug_phase_ticks(fccqp_solver *s, long long *out, long long count) {
 int fccqp_debug_read_workspace(fccqp_solver *s, double *out, long long count, long long *available) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   DeviceGuard g(s->device);
-  if (s->solved) HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, wait_last(s));
   const long long have = s->dwork ? (long long)s->batch * s->work_stride : 0;
   if (available) *available = have;
   const long long take = count < have ? count : have;

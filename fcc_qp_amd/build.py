@@ -68,6 +68,13 @@ def build_lib(force: bool = False) -> str:
                 # fused kernel: loop headers on 256-byte boundaries -- its ADMM loop ran 5 % slower or faster
                 # with nothing but its placement in the code (the generic kernel, full of short loops, loses 2 %)
                 align = ["-falign-loops=256"] if ("fused" in os.path.basename(src) or "coop" in os.path.basename(src)) else []
+                # generic kernel: NO real function calls (every device function inlined).  With real calls the 8-slot
+                # instantiation (256 < N <= 512: 256 VGPRs + 256 AGPRs, callee-saved registers parked in AGPRs, scratch)
+                # returned wrong, run-to-run different results on MI355X -- z off by 1e-10 .. 1e+3, or NaN, depending
+                # on the box -- while the same source with this switch is exact and bit-reproducible (same box,
+                # alternating runs: tools/n512_probe.py).  Costs ~1.5 min of compile time.
+                if os.path.basename(src) == "fccqp_generic.hip":
+                    align = align + ["-mllvm", "-amdgpu-function-calls=false"]
                 _run([hipcc(), "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
                       "-fno-gpu-rdc", "-ffp-contract=off"] + align + ["-mllvm", "-pragma-unroll-threshold=400000",
                       "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-c", src, "-o", obj])

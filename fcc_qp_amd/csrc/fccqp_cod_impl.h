@@ -47,7 +47,7 @@ __device__ __forceinline__ double wmax(double v) {
 template <bool LDSW>
 __device__ __forceinline__ void wsync() {
   if constexpr (LDSW) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  else agent_release_acquire();            // waits written out: see fccqp_device.h
   __builtin_amdgcn_wave_barrier();
 }
 

@@ -37,6 +37,8 @@ namespace coop {
 using namespace fused;
 
 __device__ __forceinline__ void wg_barrier() {
+  // (the LDS wait written out: the compiler's own is not relied on, see agent_release() in fccqp_device.h)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

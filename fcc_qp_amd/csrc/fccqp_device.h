@@ -93,6 +93,46 @@ __device__ __forceinline__ int block_instance(const KernelArgs &a) {
   return (int)t;
 }
 
+// ---- memory fences with their waits WRITTEN OUT ----------------------------------------------------------------
+// Lanes (and waves) hand data to each other through global memory in the generic kernel's large shapes (the packed
+// KKT matrix in a per-block workspace: the owner of an entry changes from phase to phase) and through a staging
+// buffer.  Between phases the writing wave must have its stores COMPLETE, then drop its L1 lines:
+//     s_waitcnt vmcnt(0) | buffer_wbl2 sc1 | s_waitcnt vmcnt(0) | buffer_inv sc1 | s_waitcnt vmcnt(0)
+// __builtin_amdgcn_fence(seq_cst, "agent") alone is NOT reliable for that with ROCm 7.2's LLVM: its wait-count pass can
+// lose track of stores issued before an EXEC-skipped region (s_cbranch_execz over the code that holds the
+// `s_waitcnt vmcnt(0)` it placed) and then emits `buffer_wbl2 sc1; s_waitcnt lgkmcnt(0); buffer_inv sc1` -- no vmcnt
+// wait on that path (seen in the disassembly of generic_kernel<8, false>: flat_store ... s_cbranch_execz ... fence).
+// The stores are then still in flight when the L1 is invalidated, and the next phase's loads are served the PREVIOUS
+// phase's values from L2.  This is the cause of the "sporadically wrong iterates" that made round 2 withdraw N > 256:
+// ADMM sweeps that read the presolve's factor (rho = 0) instead of the K_rho factor just written over it -- results
+// off by O(rho), different from run to run, correct whenever no presolve phase ran before (tools/n512_bisect*.py,
+// DESIGN.md section 7).  Inline asm is opaque to the pass, so the waits below always survive
+// (MI355X_MICROARCH.md "Compiler hazard" describes the same trap for cross-CU hand-offs).
+// (-DFCCQP_NO_EXPLICIT_WAITS builds the compiler's own lowering again: tools/n512_variants.sh, for the record)
+#ifdef FCCQP_NO_EXPLICIT_WAITS
+#define FCCQP_EXPLICIT_WAIT(what)
+#else
+#define FCCQP_EXPLICIT_WAIT(what) asm volatile(what ::: "memory")
+#endif
+__device__ __forceinline__ void agent_release() {
+  FCCQP_EXPLICIT_WAIT("s_waitcnt vmcnt(0) lgkmcnt(0)");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  FCCQP_EXPLICIT_WAIT("s_waitcnt vmcnt(0)");
+}
+__device__ __forceinline__ void agent_acquire() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  FCCQP_EXPLICIT_WAIT("s_waitcnt vmcnt(0)");      // (the invalidate completes asynchronously)
+}
+__device__ __forceinline__ void agent_release_acquire() {
+  agent_release();
+  agent_acquire();
+}
+// workgroup barrier whose LDS and global traffic is complete on arrival, whatever the pass thinks is pending
+__device__ __forceinline__ void workgroup_sync() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // flag bits (mirror include/fccqp.h)
 constexpr int kFlagPresolveRan = 1;
 constexpr int kFlagPresolveNumerical = 2;
@@ -101,15 +141,12 @@ constexpr int kFlagEqualityOnly = 8;
 constexpr int kFlagPresolveCod = 16;
 
 // ---- generic kernel (fccqp_generic.hip) -----------------------------------------------------
-// Largest KKT size N = n + m the generic kernel handles (4 register slots x 64 lanes; the reference's
-// shapes are N = 98 and, in BASELINE configs[3], N = 174).  An 8-slot instantiation for N up to 512
-// existed in round 1 and was withdrawn in round 2: its first GPU tests (N = 260 ... 512) returned
-// sporadically wrong iterates -- the KKT factor it left in memory was right, the triangular sweeps
-// that read it were not; which runs failed changed from GPU box to GPU box and from build to build,
-// bounds-checked accesses found nothing out of range, and agent-scope fences, a rewrite of the
-// factorisation with static row ownership and exact-slot instantiations each only moved the failures
-// (DESIGN.md section 7).  fccqp_create returns FCCQP_ERR_UNSUPPORTED beyond this size.
-constexpr int kGenericMaxN = 256;
+// Largest KKT size N = n + m the generic kernel handles (8 register slots x 64 lanes; the reference's
+// shapes are N = 98 and, in BASELINE configs[3], N = 174).  Round 2 had withdrawn N > 256 after sporadically
+// wrong iterates whose cause it could not establish; the cause is the fence lowering described at
+// agent_release() above (it was latent in the 4-slot global-workspace path, 198 < N <= 256, too), and the range is
+// back.  fccqp_create returns FCCQP_ERR_UNSUPPORTED beyond this size.
+constexpr int kGenericMaxN = 512;
 // Bytes of dynamic LDS the generic kernel needs when the packed KKT lives in LDS.
 size_t generic_lds_bytes(int n, int m, int nc);
 // Doubles of global workspace per block when the packed KKT does not fit in LDS (else 0).

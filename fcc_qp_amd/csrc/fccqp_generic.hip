@@ -47,14 +47,12 @@ __device__ __forceinline__ void wave_sync() {
 
 // Matrix in the per-block GLOBAL workspace (N > 198): the lanes of the wave hand matrix entries to each
 // other through memory, and the owner of an entry changes from phase to phase (assembly: lane =
-// column; factorisation: lane = row - k - 1; solves: lane = row).  Between phases the wave's writes
-// are pushed to L2 and its L1 lines dropped (agent-scope release + acquire: buffer_wbl2 / buffer_inv).
-// The wavefront-scope fence alone, which is all the memory model asks for inside one wave, gave
-// sporadically wrong results in the second phase of a solve on some MI355X boxes and not on others
-// (re-assembly over the presolve's factor, whose lines were still in L1; found by the N = 257..512
-// tests of tests/test_gpu_reference_quirks.py) -- measured, not explained.
+// column; factorisation: lane = row - k - 1; solves: lane = row).  Between phases the wave's stores must be
+// complete and its L1 lines dropped: agent_release_acquire() (fccqp_device.h), with the waits written out --
+// the plain agent-scope fence lost its `s_waitcnt vmcnt(0)` on one control path of the 8-slot kernel, which is what
+// produced the sporadically wrong iterates of round 2's N > 256 tests.
 __device__ __forceinline__ void global_phase_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  agent_release_acquire();
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -873,11 +871,11 @@ __device__ __forceinline__ void invert_diag_blocks_share(lds_f64 *M, const int N
     for (int k = 0; k < i; ++k) y[i] = fma(-((i < nrow) ? l[k] : 0.0), y[k], y[i]);
   }
   // every lane (of every wave) has read its block before any block is overwritten
-  if constexpr (MULTI) __syncthreads(); else wave_sync();
+  if constexpr (MULTI) workgroup_sync(); else wave_sync();
 #pragma unroll
   for (int i = 1; i < 16; ++i)
     if (live && i > j && r0 + i < N) M[col_base(r0 + j, N) + r0 + i] = y[i];
-  if constexpr (MULTI) __syncthreads(); else wave_sync();
+  if constexpr (MULTI) workgroup_sync(); else wave_sync();
 }
 
 // A real call (noinline): inlined into the solver wave, its ~400 live registers push the solver's own
@@ -1184,7 +1182,7 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
   bool have_cmd = false;                               // the operator loop below leaves with the next command read
   for (;;) {
     if (!have_cmd) {
-      __syncthreads();                                 // A: a command is posted
+      workgroup_sync();                                 // A: a command is posted
       cmd = (int)ctrl[0];
     }
     have_cmd = false;
@@ -1193,7 +1191,7 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       const TIN *Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
       const TIN *A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * (N - n) * n;
       assemble_share<TIN>(M, Q, A, n, N, (double)ctrl[1], lane, wave, WAVES);
-      __syncthreads();                                 // B: the matrix is complete
+      workgroup_sync();                                 // B: the matrix is complete
       continue;
     }
     if (cmd == kCmdMatvec) {                           // (LDS-resident G) this wave's quarter of the columns
@@ -1205,13 +1203,13 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       lds_f64 *part = M + g_part_off(n);
 #pragma unroll
       for (int t = 0; t < GS; ++t) part[wave * 2 * kWave + lane + kWave * t] = acc0[t] + acc1[t];
-      __syncthreads();                                 // B
+      workgroup_sync();                                 // B
       continue;
     }
     if (cmd == kCmdFactor) {
       const bool bad = ldlt_factor_share<SLOTS>(M, N, lane, wave, WAVES, ctrl + 2, (double)ctrl[1]);
       if (lane == 0) ctrl[3 + wave] = bad ? 1.0 : 0.0;
-      __syncthreads();                                 // B: factorisation complete
+      workgroup_sync();                                 // B: factorisation complete
       continue;
     }
     double *stage = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
@@ -1221,14 +1219,14 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       for (int b = wave; b * RB <= n; b += WAVES)
         g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, a.rho, stage, nullptr, nullptr, nullptr);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();                                   // B: every column of G is staged, L is dead
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    agent_release();
+    workgroup_sync();                                   // B: every column of G is staged, L is dead
+    agent_acquire();
     if ((double)ctrl[1] != 0.0) {                      // the solver wave wants x0 out of G first:
-      __syncthreads();                                 // B2: ... it has built W = I - rho G in LDS;
+      workgroup_sync();                                 // B2: ... it has built W = I - rho G in LDS;
       const bool wb = ldlt_factor_share<(SLOTS < 2 ? SLOTS : 2)>(M, n, lane, wave, WAVES, ctrl + 2, kPresolveMinPivot);
       if (lane == 0) ctrl[3 + wave] = wb ? 1.0 : 0.0;  // the n x n factorisation is shared like the KKT one
-      __syncthreads();                                 // B3: W is factorised (the solver wave solves alone)
+      workgroup_sync();                                 // B3: W is factorised (the solver wave solves alone)
     }
     if (mv_regs) {
       // rho G stays out of LDS: this wave's columns into registers (staged column-major, global / L2).
@@ -1249,11 +1247,11 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
           }
         }
       }
-      __syncthreads();                                 // C: G is in place
+      workgroup_sync();                                 // C: G is in place
       const lds_f64 *wbuf = M + g_w_off(n);
       lds_f64 *part = M + g_w_off(n) + kMvWLen;
       for (;;) {
-        __syncthreads();                               // A
+        workgroup_sync();                               // A
         cmd = (int)ctrl[0];
         if (cmd != kCmdMatvec) { have_cmd = true; break; }
         double Wq[kMvBlocks];
@@ -1265,7 +1263,7 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
         dpp_mv_rows<0>(acc, Wq, Greg);
         part[wave * 2 * kWave + lane] = acc[0][0] + acc[0][1];
         part[wave * 2 * kWave + kWave + lane] = acc[1][0] + acc[1][1];
-        __syncthreads();                               // B
+        workgroup_sync();                               // B
       }
       continue;
     }
@@ -1274,7 +1272,7 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
 #pragma unroll 8
       for (int e = wave * kWave + lane; e < total; e += WAVES * kWave) M[e] = stage[e];
     }
-    __syncthreads();                                   // C: G is in LDS
+    workgroup_sync();                                   // C: G is in LDS
   }
 }
 
@@ -1350,9 +1348,9 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
       // all four waves fetch (the lone wave would otherwise sit through ~40 dependent HBM round trips)
       lds_f64 *ctrl = ctrl_word(lds, N, nc);
       if (lane == 0) { ctrl[0] = (double)kCmdAssemble; ctrl[1] = rho; }
-      __syncthreads();                                 // A (see helper_wave)
+      workgroup_sync();                                 // A (see helper_wave)
       assemble_share<TIN>(M, Q, A, n, N, rho, lane, 0, WAVES);
-      __syncthreads();                                 // B
+      workgroup_sync();                                 // B
     } else {
       assemble_share<TIN>(M, Q, A, n, N, rho, lane, 0, 1);
       wave_sync();
@@ -1366,10 +1364,10 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     if constexpr (WAVES > 1) {
       volatile lds_f64 *ctrl = ctrl_word(lds, N, nc);
       if (lane == 0) { ctrl[0] = (double)kCmdFactor; ctrl[1] = tiny; ctrl[2] = 0.0; }
-      __syncthreads();                                 // A
+      workgroup_sync();                                 // A
       const bool mine = ldlt_factor_share<SLOTS>(M, N, lane, 0, WAVES, ctrl + 2, tiny);
       if (lane == 0) ctrl[3] = mine ? 1.0 : 0.0;
-      __syncthreads();                                 // B
+      workgroup_sync();                                 // B
       bool bad = false;
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) bad = bad || (ctrl[3 + w] != 0.0);
@@ -1538,7 +1536,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               }
             }
             if (lane == 0) { ctrl_word(lds, N, nc)[0] = (double)kCmdBuild; ctrl_word(lds, N, nc)[1] = with_presolve ? 1.0 : 0.0; }
-            __syncthreads();                           // A (see helper_wave)
+            workgroup_sync();                           // A (see helper_wave)
           }
           bool by_mfma = false;
           if constexpr (WAVES > 1) by_mfma = g_build_mfma_supported(N, n);
@@ -1553,8 +1551,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
                 const int i = lane + kWave * t;
                 if (i < N) gs[i] = (i < n) ? -vb[t] : vtail[t];
               }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              agent_release_acquire();
               wave_sync();
               g_build_mfma_single(M, N, n, lane, opt_rho, stage, gs);
               by_mfma = true;
@@ -1566,10 +1563,10 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               g_build_batch<SLOTS, RB, false>(M, N, n, lane, b * RB, opt_rho, stage, nullptr, nullptr, nullptr);
           }
           // the staged columns are read back by other lanes (and waves)
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          if constexpr (WAVES > 1) __syncthreads();    // B
+          agent_release();
+          if constexpr (WAVES > 1) workgroup_sync();    // B
           else wave_sync();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          agent_acquire();
           if constexpr (WAVES > 1) {
             if (by_mfma) {                             // x_c came back through LDS
               const lds_f64 *xc_s = ctrl_word(lds, N, nc) + kCtrlWords + N;
@@ -1599,10 +1596,10 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
             if constexpr (WAVES > 1) {
               volatile lds_f64 *ctrl = ctrl_word(lds, N, nc);
               if (lane == 0) ctrl[2] = 0.0;          // finished-panel count of the shared factorisation
-              __syncthreads();                       // B2
+              workgroup_sync();                       // B2
               const bool mine = ldlt_factor_share<GS>(M, n, lane, 0, WAVES, ctrl + 2, kPresolveMinPivot);
               if (lane == 0) ctrl[3] = mine ? 1.0 : 0.0;
-              __syncthreads();                       // B3
+              workgroup_sync();                       // B3
 #pragma unroll
               for (int w = 0; w < WAVES; ++w) wbad = wbad || (ctrl[3 + w] != 0.0);
             } else {
@@ -1628,7 +1625,7 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
     #pragma unroll 8
             for (int e = lane; e < total; e += WAVES * kWave) M[g_off + e] = stage[e];
           }
-          if constexpr (WAVES > 1) __syncthreads();    // C
+          if constexpr (WAVES > 1) workgroup_sync();    // C
           else wave_sync();
           g_ready = true;
           if (wbad) {
@@ -1670,8 +1667,8 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               if (mv_regs) {
                 // the helpers hold rho G in registers (helper_wave): post w, collect three partial sums
                 if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdMatvec;
-                __syncthreads();                         // A: w is in LDS
-                __syncthreads();                         // B: the helpers' partial sums are in LDS
+                workgroup_sync();                         // A: w is in LDS
+                workgroup_sync();                         // B: the helpers' partial sums are in LDS
                 const lds_f64 *part = M + w_off + kMvWLen;
       #pragma unroll
                 for (int w = 1; w < WAVES; ++w) {
@@ -1682,9 +1679,9 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
                 // the four waves take a quarter of the columns each; partial sums meet in LDS
                 const int per = (nchunk + WAVES - 1) / WAVES;
                 if (lane == 0) ctrl_word(lds, N, nc)[0] = (double)kCmdMatvec;
-                __syncthreads();                         // A: w is in LDS
+                workgroup_sync();                         // A: w is in LDS
                 matvec_range<GS>(M, n, lane, 0, (per < nchunk) ? per : nchunk, acc0, acc1);
-                __syncthreads();                         // B: the helpers' partial sums are in LDS
+                workgroup_sync();                         // B: the helpers' partial sums are in LDS
                 const lds_f64 *part = M + g_part_off(n);
       #pragma unroll
                 for (int w = 1; w < WAVES; ++w) {
@@ -1857,7 +1854,7 @@ __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void gene
       solve_instance<SLOTS, MAT_IN_LDS, TIN, SHP>(a, lds, inst, from_list);
       if constexpr (WAVES > 1) {
         if (lane == 0) ctrl_word(lds, SHP::fixed ? SHP::n + SHP::m : a.n + a.m, SHP::fixed ? SHP::nc : a.nc)[0] = (double)kCmdDone;
-        __syncthreads();
+        workgroup_sync();
       }
     } else {
       if constexpr (WAVES > 1) helper_wave<SLOTS, WAVES, TIN, SHP>(a, lds, inst, wave, lane);
@@ -1876,7 +1873,7 @@ __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void gene
         const int c = block_instance(a);
         if (lane == 0) claimed = c;
       }
-      __syncthreads();
+      workgroup_sync();
       inst = claimed;
     } else {
       inst = block_instance(a);
@@ -1976,7 +1973,7 @@ static hipError_t launch_generic_blocks(const KernelArgs &a_in, size_t lds_limit
     case 2: return launch_slots<2, TIN>(a, in_lds, lds, blocks, stream);
     case 3: return launch_slots<3, TIN>(a, in_lds, lds, blocks, stream);
     case 4: return launch_slots<4, TIN>(a, in_lds, lds, blocks, stream);
-    default: return hipErrorInvalidValue;            // N > kGenericMaxN is refused at fccqp_create
+    default: return launch_slots<8, TIN>(a, in_lds, lds, blocks, stream);     // 256 < N <= 512 (kGenericMaxN)
   }
 }
 

@@ -173,3 +173,46 @@ def test_lane_selects_keep_their_wait_states(objects):
             bad = lane_select_hazards(body)
             assert not bad, f"{name}: {len(bad)} lane-select hazards, first: {bad[0][1]}"
     assert n > 100
+
+
+def _is_vmem(mn):
+    return mn.startswith(("global_", "flat_", "scratch_", "buffer_load", "buffer_store", "buffer_atomic"))
+
+
+def test_agent_fences_carry_their_store_waits(objects):
+    """Every `buffer_wbl2 sc1` (agent-scope release) in the library must have an `s_waitcnt vmcnt(0)` between it and
+    the last vector-memory instruction before it, and another before the first one after it; every `buffer_inv sc1`
+    (acquire) must be followed by one before the next vector-memory instruction: the written-out waits of
+    agent_release() / agent_acquire() (fccqp_device.h).  (Scalar / vector ALU instructions may be scheduled in
+    between; memory instructions cannot cross the asm statements.)  The compiler's own lowering of the fence dropped
+    the vmcnt wait on one control path of generic_kernel<8, false> -- the cause of round 2's wrong iterates at N > 256."""
+    def wait_before(body, i):
+        j = i - 1
+        while j >= 0 and not _is_vmem(body[j][0]) and body[j][0] not in ("buffer_wbl2", "buffer_inv"):
+            if body[j][0] == "s_waitcnt" and "vmcnt(0)" in body[j][1]:
+                return True
+            j -= 1
+        return False
+
+    def wait_after(body, i):
+        j = i + 1
+        while j < len(body) and not _is_vmem(body[j][0]):
+            if body[j][0] == "s_waitcnt" and "vmcnt(0)" in body[j][1]:
+                return True
+            if body[j][0] in ("buffer_wbl2", "buffer_inv"):        # release directly followed by the acquire
+                return wait_after(body, j) if body[j][0] == "buffer_inv" else False
+            j += 1
+        return False
+
+    n_rel = n_acq = 0
+    for _, _, dis in objects:
+        for name, body in dis.items():
+            for i, (mn, ops) in enumerate(body):
+                if mn == "buffer_wbl2":
+                    n_rel += 1
+                    assert wait_before(body, i), f"{name}: release at {i}: no s_waitcnt vmcnt(0) behind the last memory instruction"
+                    assert wait_after(body, i), f"{name}: release at {i}: no s_waitcnt vmcnt(0) before the next memory instruction"
+                if mn == "buffer_inv":
+                    n_acq += 1
+                    assert wait_after(body, i), f"{name}: acquire at {i}: no s_waitcnt vmcnt(0) before the next memory instruction"
+    assert n_rel >= 8 and n_acq >= 8, (n_rel, n_acq)

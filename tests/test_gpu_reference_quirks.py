@@ -109,13 +109,17 @@ def test_finite_bounds_on_contact_variables_odd_shape(oracle):
     assert_residual_fields(d, det_ref, it, it_ref, "bounded lambda_c odd shape")
 
 
-# ---- (c) shapes whose KKT does not fit in LDS: per-block global workspace (198 < N <= 256) ------------
-# (Round 1 advertised N up to 512 through an 8-slot instantiation that no test had run; its first
-# tests failed sporadically and the range above 256 was withdrawn: fccqp_device.h)
+# ---- (c) shapes whose KKT does not fit in LDS: per-block global workspace (198 < N <= 512) ------------
+# (Round 2 withdrew N > 256 after sporadically wrong iterates; round 3 found the cause -- an agent-scope fence
+# lowered without its `s_waitcnt vmcnt(0)` on one control path, so that sweeps read the presolve's factor through
+# stale L2 data -- wrote the waits out (agent_release / agent_acquire, fccqp_device.h) and restored the range.)
 @pytest.mark.parametrize("dims", [(140, 60, 12, 100),     # N = 200: just past the LDS limit
                                   (160, 70, 30, 120),     # N = 230
-                                  (196, 60, 12, 100),     # N = 256: the maximum, all four slots full
-                                  (130, 126, 9, 100)])    # N = 256 with as many equality rows as the shape allows
+                                  (196, 60, 12, 100),     # N = 256: all four slots of the 4-slot kernel full
+                                  (130, 126, 9, 100),     # N = 256 with as many equality rows as the shape allows
+                                  (180, 80, 12, 100),     # N = 260: first shape of the 8-slot kernel, five slots used
+                                  (250, 134, 12, 100),    # N = 384
+                                  (300, 212, 9, 100)])    # N = 512: the maximum, all eight slots full
 def test_global_workspace_shapes_match_oracle(oracle, dims):
     from tests.test_gpu_parity import _random_qp
     n, m, nc, s = dims
@@ -133,21 +137,44 @@ def test_global_workspace_shapes_match_oracle(oracle, dims):
 
 
 def test_shapes_beyond_the_supported_size_are_refused():
-    """N = n + m > 256: FCCQP_ERR_UNSUPPORTED at construction (documented limit), not a wrong answer."""
+    """N = n + m > 512: FCCQP_ERR_UNSUPPORTED at construction (documented limit), not a wrong answer."""
     L = CAPI.lib()
     import ctypes
     h = ctypes.c_void_p()
-    assert L.fccqp_create(200, 57, 12, 100, 1, 0, ctypes.byref(h)) == CAPI.ERR_UNSUPPORTED
-    assert L.fccqp_create(330, 182, 9, 300, 1, 0, ctypes.byref(h)) == CAPI.ERR_UNSUPPORTED
-    assert L.fccqp_create(196, 60, 12, 100, 1, 0, ctypes.byref(h)) == CAPI.OK
+    assert L.fccqp_create(400, 113, 12, 100, 1, 0, ctypes.byref(h)) == CAPI.ERR_UNSUPPORTED
+    assert L.fccqp_create(600, 182, 9, 300, 1, 0, ctypes.byref(h)) == CAPI.ERR_UNSUPPORTED
+    assert L.fccqp_create(330, 182, 9, 300, 1, 0, ctypes.byref(h)) == CAPI.OK       # N = 512
     L.fccqp_destroy(h)
 
 
-def test_global_workspace_warm_chain_and_rank_deficient_presolve(oracle):
-    """N = 230 (matrix in the global workspace): a warm-started chain, and a cold batch in which one
-    instance has a dead variable (zero row of K: the reference's COD branch)."""
+def test_global_workspace_phases_do_not_see_each_other_stale(oracle):
+    """The failure mode behind round 2's withdrawal of N > 256, pinned: a cold solve runs a presolve phase (assemble K,
+    factorise, sweep) and then re-assembles K_rho over that factor in the same global workspace; with the fence
+    between the phases lowered without its store wait, the ADMM sweeps read the presolve's factor and z was off by
+    O(rho), differently from run to run.  Here: one iteration and two, cold, six fresh handles each, every result
+    within rounding of the oracle AND bit-identical across the repetitions -- for the 4-slot and the 8-slot kernel."""
+    from tests.test_gpu_parity import _random_qp
+    for dims in ((160, 70, 30, 120), (180, 80, 12, 100), (300, 212, 9, 100)):
+        n, m, nc, s = dims
+        rng = np.random.default_rng(sum(dims))
+        B = P.stack([_random_qp(rng, n, m, nc, s) for _ in range(2)])
+        for max_iter in (1, 2):
+            opts = dict(max_iter=max_iter, rho=0.1, eps_fcone=1e-7, eps_bound=1e-7)
+            z_ref, it_ref, _, _ = oracle.solve_batch(dims, opts, *B.arrays(), nthreads=2)
+            first = None
+            for rep in range(6):
+                z, it, d, solver = gpu_solve(dims, opts, B)
+                solver.close()
+                assert rel_err(z, z_ref).max() <= 1e-10, (dims, max_iter, rep, rel_err(z, z_ref))
+                first = z if first is None else first
+                assert np.array_equal(z, first), (dims, max_iter, rep)
+
+
+@pytest.mark.parametrize("dims", [(160, 70, 30, 120), (250, 134, 30, 120)], ids=["N230", "N384"])
+def test_global_workspace_warm_chain_and_rank_deficient_presolve(oracle, dims):
+    """N = 230 / 384 (matrix in the global workspace, 4- and 8-slot kernel): a warm-started chain, and a cold batch in
+    which one instance has a dead variable (zero row of K: the reference's COD branch)."""
     from tests.test_gpu_parity import _random_qp, _dead_variable
-    dims = (160, 70, 30, 120)
     n, m, nc, s = dims
     rng = np.random.default_rng(99)
     chains, steps = 2, 3
@@ -167,14 +194,14 @@ def test_global_workspace_warm_chain_and_rank_deficient_presolve(oracle):
         for c, o in enumerate(orcs):
             o.set_warm_start(t > 0); o.Solve(**seqs[c][t]); sol = o.GetSolution()
             z_ref[c] = sol.z; it_ref.append(sol.details.n_iter)
-        assert_parity(z, [x.n_iter for x in d], z_ref, it_ref, tol=Z_TOL, what=f"N=230 chain step {t}")
+        assert_parity(z, [x.n_iter for x in d], z_ref, it_ref, tol=Z_TOL, what=f"N={n + m} chain step {t}")
     qps = [_random_qp(rng, n, m, nc, s) for _ in range(3)]
     qps[1] = _dead_variable(qps[1], 7)
     B = P.stack(qps)
     z_ref, it_ref, det_ref, _ = oracle.solve_batch(dims, opts, *B.arrays(), nthreads=3)
     assert [det_ref[i].presolve_ldlt_info for i in range(3)] == [0, 1, 0]
     z, it, d, _ = gpu_solve(dims, opts, B)
-    assert_parity(z, it, z_ref, it_ref, tol=Z_TOL, what="N=230 cod")
+    assert_parity(z, it, z_ref, it_ref, tol=Z_TOL, what=f"N={n + m} cod")
     assert [bool(x.flags & CAPI.FLAG_PRESOLVE_COD) for x in d] == [False, True, False]
 
 

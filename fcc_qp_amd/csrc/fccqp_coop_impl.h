@@ -652,13 +652,13 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       // (double-buffered by iteration parity: a wave may write the next partial sums while a slower one still
       // reads these; the barrier of the next iteration separates it from the one after)
       lds_f64 *const pp = part + (iter & 1) * CS * SH::kPos;
-      pp[c * SH::kPos + pos] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      pp[c * SH::kPos + pos] = mv_total(acc);
       wg_barrier();
       x = xc;
 #pragma unroll
       for (int cc = 0; cc < CS; ++cc) x += pp[cc * SH::kPos + pos];
     } else {
-      x = xc + ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      x = xc + mv_total(acc);
     }
     const double xm = x + mulc;
     const double cfx = quad_bcast<0>(xm), cfy = quad_bcast<1>(xm), cfz = quad_bcast<2>(xm);

@@ -935,28 +935,61 @@ __device__ __forceinline__ void solve_lds_one_slot(const lds_f64 *M, const int l
 // hazard recogniser counts an inline-asm statement as zero wait states, so with one statement per FMA
 // it put an s_nop in front of every reuse of an accumulator whatever the distance (a dependent fp64 FMA
 // needs none).  Unused operands of the shorter last block are legal.
+// Accumulators of the mat-vec: the DPP FMA issues every ~8.2 cycles with a fresh matrix operand whether it depends on
+// the previous one or not and whatever the number of accumulators (tools/vgpr_bank_probe.hip), so ONE accumulator
+// costs nothing and saves the zeroing of the others and the three adds of the final sum.  (-DFCCQP_MV_FOUR_ACC: the
+// four rotating accumulators of round 2.)
+#ifdef FCCQP_MV_FOUR_ACC
+constexpr bool kMvOneAcc = false;
+#define FCCQP_A0 0
+#define FCCQP_A1 1
+#define FCCQP_A2 2
+#define FCCQP_A3 3
+#else
+constexpr bool kMvOneAcc = true;
+#define FCCQP_A0 0
+#define FCCQP_A1 0
+#define FCCQP_A2 0
+#define FCCQP_A3 0
+#endif
 constexpr int kMvAcc = 4;
-#define FCCQP_DPPF(A, M, L) "v_fmac_f64_dpp %" #A ", %4, %" #M " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
-#define FCCQP_S1 FCCQP_DPPF(0, 5, 0)
-#define FCCQP_S2 FCCQP_S1 FCCQP_DPPF(1, 6, 1)
-#define FCCQP_S3 FCCQP_S2 FCCQP_DPPF(2, 7, 2)
-#define FCCQP_S4 FCCQP_S3 FCCQP_DPPF(3, 8, 3)
-#define FCCQP_S5 FCCQP_S4 FCCQP_DPPF(0, 9, 4)
-#define FCCQP_S6 FCCQP_S5 FCCQP_DPPF(1, 10, 5)
-#define FCCQP_S7 FCCQP_S6 FCCQP_DPPF(2, 11, 6)
-#define FCCQP_S8 FCCQP_S7 FCCQP_DPPF(3, 12, 7)
-#define FCCQP_S9 FCCQP_S8 FCCQP_DPPF(0, 13, 8)
-#define FCCQP_S10 FCCQP_S9 FCCQP_DPPF(1, 14, 9)
-#define FCCQP_S11 FCCQP_S10 FCCQP_DPPF(2, 15, 10)
-#define FCCQP_S12 FCCQP_S11 FCCQP_DPPF(3, 16, 11)
-#define FCCQP_S13 FCCQP_S12 FCCQP_DPPF(0, 17, 12)
-#define FCCQP_S14 FCCQP_S13 FCCQP_DPPF(1, 18, 13)
-#define FCCQP_S15 FCCQP_S14 FCCQP_DPPF(2, 19, 14)
-#define FCCQP_S16 FCCQP_S15 FCCQP_DPPF(3, 20, 15)
+__device__ __forceinline__ double mv_total(const double (&acc)[kMvAcc]) {
+  if constexpr (kMvOneAcc) return acc[0];
+  else return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+#define FCCQP_DPPF_X(A, M, L) "v_fmac_f64_dpp %" #A ", %4, %" #M " row_newbcast:" #L " row_mask:0xf bank_mask:0xf\n\t"
+#define FCCQP_DPPF(A, M, L) FCCQP_DPPF_X(A, M, L)
+#define FCCQP_S1 FCCQP_DPPF(FCCQP_A0, 5, 0)
+#define FCCQP_S2 FCCQP_S1 FCCQP_DPPF(FCCQP_A1, 6, 1)
+#define FCCQP_S3 FCCQP_S2 FCCQP_DPPF(FCCQP_A2, 7, 2)
+#define FCCQP_S4 FCCQP_S3 FCCQP_DPPF(FCCQP_A3, 8, 3)
+#define FCCQP_S5 FCCQP_S4 FCCQP_DPPF(FCCQP_A0, 9, 4)
+#define FCCQP_S6 FCCQP_S5 FCCQP_DPPF(FCCQP_A1, 10, 5)
+#define FCCQP_S7 FCCQP_S6 FCCQP_DPPF(FCCQP_A2, 11, 6)
+#define FCCQP_S8 FCCQP_S7 FCCQP_DPPF(FCCQP_A3, 12, 7)
+#define FCCQP_S9 FCCQP_S8 FCCQP_DPPF(FCCQP_A0, 13, 8)
+#define FCCQP_S10 FCCQP_S9 FCCQP_DPPF(FCCQP_A1, 14, 9)
+#define FCCQP_S11 FCCQP_S10 FCCQP_DPPF(FCCQP_A2, 15, 10)
+#define FCCQP_S12 FCCQP_S11 FCCQP_DPPF(FCCQP_A3, 16, 11)
+#define FCCQP_S13 FCCQP_S12 FCCQP_DPPF(FCCQP_A0, 17, 12)
+#define FCCQP_S14 FCCQP_S13 FCCQP_DPPF(FCCQP_A1, 18, 13)
+#define FCCQP_S15 FCCQP_S14 FCCQP_DPPF(FCCQP_A2, 19, 14)
+#define FCCQP_S16 FCCQP_S15 FCCQP_DPPF(FCCQP_A3, 20, 15)
+// (with one accumulator the other three are not operands of the statement at all: as "+v" operands they would
+// have to be materialised -- three v_mov_b64 per iteration -- although the instructions never name them; the
+// operand numbers %1 .. %3 are kept by three dummy inputs that cost nothing)
+#ifdef FCCQP_MV_FOUR_ACC
 #define FCCQP_DPP_BLOCK(STR)                                                                          \
   asm(STR : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                    \
       : "v"(w), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), \
         "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]))
+#else
+#define FCCQP_DPP_BLOCK(STR)                                                                          \
+  asm(STR : "+v"(acc[0])                                                                              \
+      : "n"(0), "n"(0), "n"(0),                                                                       \
+        "v"(w), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3]), "v"(m[4]), "v"(m[5]), "v"(m[6]), "v"(m[7]), \
+        "v"(m[8]), "v"(m[9]), "v"(m[10]), "v"(m[11]), "v"(m[12]), "v"(m[13]), "v"(m[14]), "v"(m[15]))
+#endif
 template <int L>
 __device__ __forceinline__ void dpp_block(double (&acc)[kMvAcc], const double w, const double (&m)[16]) {
   static_assert(L >= 1 && L <= 16, "one 16-lane row");
@@ -1103,7 +1136,7 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
     else if constexpr (NQ == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
     else asm volatile("s_nop 1" : "+v"(Wq[0]));
     dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
-    x = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    x = mv_total(acc);
     // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in lanes 4c .. 4c+2 of
     // this lane's quad: three quad_perm broadcasts (v_mov_b32 DPP pairs), no LDS round trip
     const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused

@@ -57,6 +57,29 @@ def test_option_sets_match_oracle(oracle, options, kernel):
     assert_parity(z, it, z_ref, it_ref, tol=Z_TOL, what=str(options))
 
 
+@pytest.mark.parametrize("rho", [1.0, 100.0])
+@pytest.mark.parametrize("wl", ["W-sat", "W-psd"])
+def test_large_rho_presolve_out_of_the_k_rho_factorisation(oracle, wl, rho):
+    """The cold-start presolve x0 = (I - rho G)^-1 x_c (all three kernels) instead of the reference's direct
+    factorisation of K (fcc_qp.cpp:159-178): W's pivots are lambda / (lambda + rho), so both its conditioning and the
+    absolute pivot cut-off (kPresolveMinPivot) depend on the user-settable rho: W = I - rho G cancels
+    log10(1 + rho / lambda_min) digits.  Measured envelope, recorded here: at rho = 1 (2e4 times the harness value)
+    x0 (max_iter = 0) and the iterates match the oracle -- which factorises K directly -- within the contract's 1e-6
+    on both workloads; at rho = 100 (2e6 times) still on W-sat, and within 1e-5 on the semi-definite W-psd (observed
+    1.0e-6).  No instance is sent to the COD pass.  (The reference's defaults and harness use rho = 1e-6 and 5e-5.)"""
+    for shape, kernels, nb in ((P.WALKING, (CAPI.KERNEL_FUSED, CAPI.KERNEL_GENERIC, CAPI.KERNEL_COOP), 24),
+                               (P.LARGE, (CAPI.KERNEL_COOP,), 6)):
+        B = P.workload(wl, nb, shape)
+        for max_iter in (0, 30):
+            opts = dict(max_iter=max_iter, rho=rho, eps_fcone=1e-6, eps_bound=1e-6)
+            z_ref, it_ref, _ = oracle_batch(oracle, shape.ctor_args, opts, B)
+            for kernel in kernels:
+                z, it, d, _ = gpu_solve(shape, opts, B, kernel)
+                tol = 1e-5 if (rho > 10.0 and wl == "W-psd") else Z_TOL
+                assert_parity(z, it, z_ref, it_ref, tol=tol, what=f"{wl} rho={rho} k{kernel} {shape.ctor_args} it{max_iter}")
+                assert not any(x.flags & (CAPI.FLAG_PRESOLVE_NUMERICAL | CAPI.FLAG_PRESOLVE_COD) for x in d)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_large_shape_matches_oracle(oracle, kernel):
     B = P.workload("W-mix", 24, P.LARGE)

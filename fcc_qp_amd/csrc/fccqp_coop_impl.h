@@ -79,8 +79,11 @@ struct Shape {
     return (in_quad && r < 3) ? s + 3 * q + r : ((k < n - nc) ? other : -1);
   }
   // ---- LDS carve (doubles) ----
-  static constexpr int kSblk = 0, kSinv = 256, kSrcp = 512;            // diagonal tile exchange (tile, L^-1, 1/d)
-  static constexpr int kRcp = 528;                                      // 1/d of every row of K_rho (16 NRB)
+  // diagonal tile exchange: the tile on its way to the column-per-lane layout (owner only), then L^-1 and 1/d in
+  // TWO slots by panel parity: the owner of column p + 1 factorises its diagonal tile while the others are still in
+  // the trailing update of panel p (look-ahead), whose L^-1 / 1/d must stay readable until every wave has passed on
+  static constexpr int kSblk = 0, kSinv = 256, kSrcp = 768;            // Sinv[2][256], Srcp[2][16]
+  static constexpr int kRcp = 800;                                      // 1/d of every row of K_rho (16 NRB)
   static constexpr int kRhs = kRcp + 16 * NRB;                          // [-b; b_eq]; later x_c, x0
   static constexpr int kRhsLen = cmax(16 * NRB, kPos + 64);
   static constexpr int kRed = kRhs + kRhsLen;                           // end-of-solve reductions [RH][4]
@@ -169,9 +172,10 @@ __device__ __forceinline__ d4 tile_fetch(const lds_f64 *buf, const int lane) {
 
 // diagonal tile of a panel: the owner factorises it and leaves L^-1 (strictly lower part) and 1/d in the exchange area
 template <int kValid, bool WITH_INVERSE>
-__device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &Cpp, double (&T)[16], double &rmine, const double max_rcp) {
+__device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &Cpp, double (&T)[16], double &rmine, const double max_rcp,
+                                          const int slot) {
   const int col = lane & 15, grp = lane >> 4;
-  lds_f64 *const Sblk = L + 0, *const Sinv = L + 256, *const Srcp = L + 512;
+  lds_f64 *const Sblk = L + 0, *const Sinv = L + 256 + 256 * slot, *const Srcp = L + 768 + 16 * slot;
 #pragma unroll
   for (int r = 0; r < 4; ++r) Sblk[16 * col + grp + 4 * r] = Cpp[r];
   lds_fence();
@@ -219,23 +223,25 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     }
     return t;
   };
+  // the diagonal tile of panel Pn, by its owner: L^-1 and 1/d into slot Pn & 1, 1/d also into the per-row table
+  auto factor_diag = [&](auto pn) {
+    constexpr int Pn = decltype(pn)::value;
+    constexpr int kValid = (N - 16 * Pn < 16) ? N - 16 * Pn : 16;
+    double T[16], rmine;
+    const bool bad = diag_tile<kValid, true>(L, lane, C[Pn][Pn], T, rmine, 0.0, Pn & 1);
+    if (lane < 16) L[SH::kRcp + 16 * Pn + col] = rmine;
+    if (bad && lane == 0) iflags[0] = 1;
+  };
+  if constexpr (SH::ownC(0) == WV) factor_diag(std::integral_constant<int, 0>{});
+  wg_barrier();
   static_for<0, NRB>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
-    constexpr int kValid = (N - 16 * P < 16) ? N - 16 * P : 16;
-    // (1) diagonal tile, by its owner
-    if constexpr (SH::ownC(P) == WV) {
-      double T[16], rmine;
-      const bool bad = diag_tile<kValid, true>(L, lane, C[P][P], T, rmine, 0.0);
-      if (lane < 16) L[SH::kRcp + 16 * P + col] = rmine;
-      if (bad && lane == 0) iflags[0] = 1;
-    }
-    wg_barrier();
     double Ainv[4], nrv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double li = Sinv[16 * (4 * r + grp) + col];
+      const double li = Sinv[256 * (P & 1) + 16 * (4 * r + grp) + col];
       Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
-      nrv[r] = -Srcp[grp + 4 * r];
+      nrv[r] = -Srcp[16 * (P & 1) + grp + 4 * r];
     }
     // (2) the own tiles of row panel P: V_pj = L^-1 C_pj (published), Y_p = L^-1 X_p
 #pragma unroll
@@ -262,16 +268,29 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     }
     if constexpr (P + 1 < NRB) {
       wg_barrier();
-      // (3) the rows below, own columns only; the A operand V_pi comes from the published tiles
+      // (3) the rows below, own columns only; the A operand V_pi comes from the published tiles.
+      // Look-ahead: the owner of column P + 1 finishes ITS diagonal tile first and factorises it at once, beside the
+      // other waves' trailing updates.  (Measured: neutral, 60.4 us either way for the large shape -- the owner's own
+      // remaining updates still queue behind its 1.5 us diagonal tile and the panel barrier waits for them; a gain
+      // would need point-to-point flags instead of the barrier.  Kept: it costs nothing and frees 13 registers.)
+      constexpr bool kOwnNext = SH::ownC(P + 1) == WV;
+      if constexpr (kOwnNext) {
+        const d4 v = tile_fetch(Vbuf + ((P & 1) * NRB + (P + 1)) * SH::kTile, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * P + 4 * r < N)
+            C[P + 1][P + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[r] * nrv[r], C[P][P + 1][r], C[P + 1][P + 1], 0, 0, 0);
+        factor_diag(std::integral_constant<int, P + 1>{});
+      }
 #pragma unroll
       for (int I = P + 1; I < NRB; ++I) {
 #pragma unroll
         for (int cb = 0; cb < NXB; ++cb)
           if (SH::ownX(cb) == WV && !zero_tile(P, cb) && P == kfirst(cb)) X[I][cb] = x_initial(I, cb);
-        // does this wave touch row block I at all?
+        // does this wave (still) touch row block I?
         bool any = false;
 #pragma unroll
-        for (int J = I; J < NRB; ++J) any = any || (SH::ownC(J) == WV);
+        for (int J = I; J < NRB; ++J) any = any || (SH::ownC(J) == WV && !(kOwnNext && I == P + 1 && J == P + 1));
 #pragma unroll
         for (int cb = 0; cb < NXB; ++cb) any = any || (SH::ownX(cb) == WV && !zero_tile(P, cb));
         if (any) {
@@ -282,7 +301,8 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
               const double aop = v[r] * nrv[r];        // A[i][k] = -(V_pi[4r + k][i] / d_{4r + k})
 #pragma unroll
               for (int J = I; J < NRB; ++J)
-                if (SH::ownC(J) == WV) C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
+                if (SH::ownC(J) == WV && !(kOwnNext && I == P + 1 && J == P + 1))
+                  C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
 #pragma unroll
               for (int cb = 0; cb < NXB; ++cb)
                 if (SH::ownX(cb) == WV && !zero_tile(P, cb))
@@ -291,6 +311,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
           }
         }
       }
+      wg_barrier();      // the next diagonal tile is published; every wave is done with the V tiles of panel P
     }
   });
 }
@@ -373,7 +394,8 @@ __device__ __forceinline__ void coop_gram(lds_f64 *L, const int lane, const doub
   wg_barrier();
 }
 
-// ---- Pw: W = U^T D U (n x n) by the same panel scheme; the factor goes packed to LDS for the two sweeps ---------
+// ---- Pw: W = U^T D U (n x n) by the same panel scheme (with the same look-ahead); the factor goes packed to LDS
+// for the two sweeps ------------------------------------------------------------------------------------------
 template <class SH, int WV>
 __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, const double min_pivot, d4 (&C)[SH::NW][SH::NW]) {
   using SW = typename SH::Reduced;
@@ -383,32 +405,35 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
   lds_f64 *const Vbuf = L + SH::kBig + SH::kWfac;
   lds_f64 *const Sblk = L + SH::kSblk, *const Sinv = L + SH::kSinv, *const Srcp = L + SH::kSrcp;
   lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
+  // diagonal tile of panel Pn, by its owner: column 16 Pn + col of L (tile_ldl leaves T = -L), 1/d in the diagonal slots
+  auto factor_diag = [&](auto pn) {
+    constexpr int Pn = decltype(pn)::value;
+    constexpr int kValid = (n - 16 * Pn < 16) ? n - 16 * Pn : 16;
+    constexpr bool kLast = (Pn + 1 == NW);
+    double T[16], rmine;
+    const bool bad = diag_tile<kValid, !kLast>(L, lane, C[Pn][Pn], T, rmine, 1.0 / min_pivot, Pn & 1);
+    if (lane < 16 && col < kValid) {
+      const int jcol = 16 * Pn + col, cb = SW::cbase(jcol);
+      M[cb + jcol] = rmine;
+#pragma unroll
+      for (int i = 1; i < kValid; ++i) {
+        lds_f64 *dst = (i > col) ? M + cb + 16 * Pn + i : Sblk + col;      // (above the diagonal: a dummy slot)
+        *dst = -T[i];
+      }
+    }
+    if (bad && lane == 0) iflags[1] = 1;
+  };
+  if constexpr (SH::ownX(0) == WV) factor_diag(std::integral_constant<int, 0>{});
+  wg_barrier();
   static_for<0, NW>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
-    constexpr int kValid = (n - 16 * P < 16) ? n - 16 * P : 16;
-    constexpr bool kLast = (P + 1 == NW);
-    if constexpr (SH::ownX(P) == WV) {
-      double T[16], rmine;
-      const bool bad = diag_tile<kValid, !kLast>(L, lane, C[P][P], T, rmine, 1.0 / min_pivot);
-      if (lane < 16 && col < kValid) {
-        const int jcol = 16 * P + col, cb = SW::cbase(jcol);
-        M[cb + jcol] = rmine;
-#pragma unroll
-        for (int i = 1; i < kValid; ++i) {
-          lds_f64 *dst = (i > col) ? M + cb + 16 * P + i : Sblk + col;      // (above the diagonal: a dummy slot)
-          *dst = -T[i];
-        }
-      }
-      if (bad && lane == 0) iflags[1] = 1;
-    }
-    if constexpr (!kLast) {
-      wg_barrier();
+    if constexpr (P + 1 < NW) {
       double Ainv[4], rv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double li = Sinv[16 * (4 * r + grp) + col];
+        const double li = Sinv[256 * (P & 1) + 16 * (4 * r + grp) + col];
         Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
-        rv[r] = Srcp[grp + 4 * r];
+        rv[r] = Srcp[16 * (P & 1) + grp + 4 * r];
       }
 #pragma unroll
       for (int J = P + 1; J < NW; ++J) {
@@ -428,11 +453,19 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
         }
       }
       wg_barrier();
+      constexpr bool kOwnNext = SH::ownX(P + 1) == WV;
+      if constexpr (kOwnNext) {              // look-ahead: the next diagonal tile first, then its factorisation
+        const d4 v = tile_fetch(Vbuf + ((P & 1) * NW + (P + 1)) * SH::kTile, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          C[P + 1][P + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[r] * -rv[r], C[P][P + 1][r], C[P + 1][P + 1], 0, 0, 0);
+        factor_diag(std::integral_constant<int, P + 1>{});
+      }
 #pragma unroll
       for (int I = P + 1; I < NW; ++I) {
         bool any = false;
 #pragma unroll
-        for (int J = I; J < NW; ++J) any = any || (SH::ownX(J) == WV);
+        for (int J = I; J < NW; ++J) any = any || (SH::ownX(J) == WV && !(kOwnNext && I == P + 1 && J == P + 1));
         if (any) {
           const d4 v = tile_fetch(Vbuf + ((P & 1) * NW + I) * SH::kTile, lane);
 #pragma unroll
@@ -440,19 +473,23 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
             const double aop = v[r] * -rv[r];
 #pragma unroll
             for (int J = I; J < NW; ++J)
-              if (SH::ownX(J) == WV) C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
+              if (SH::ownX(J) == WV && !(kOwnNext && I == P + 1 && J == P + 1))
+                C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
           }
         }
       }
+      wg_barrier();
     }
   });
-  wg_barrier();
 }
 
-// x := (L D L^T)^-1 x, rows lane + 64 t (one wave, SLOTS rows per lane), M as left by coop_factor_store
+// x := (L D L^T)^-1 x, rows lane + 64 t (one wave, SLOTS rows per lane), M as left by coop_factor_store.
+// Column-oriented substitution; the only dependent chain is v_readlane(x_k) -> fma.  The L operands of the next U
+// steps are fetched while the current U run (two register buffers, as solve_lds_one_slot of the one-wave kernel):
+// left to the compiler every step waited for its own LDS round trip (12.9 us for n = 114 instead of ~6).
 template <class SW, int SLOTS>
 __device__ __forceinline__ void solve_lds_slots(const lds_f64 *M, const int lane, double (&x)[SLOTS]) {
-  constexpr int N = SW::N;
+  constexpr int N = SW::N, U = 8;
   static_assert(N <= 64 * SLOTS, "SLOTS rows per lane");
   int rc[SLOTS], cbr[SLOTS];
 #pragma unroll
@@ -460,30 +497,72 @@ __device__ __forceinline__ void solve_lds_slots(const lds_f64 *M, const int lane
     rc[t] = (lane + 64 * t < N) ? lane + 64 * t : N - 1;
     cbr[t] = SW::cbase(rc[t]);
   }
-  // forward, unit lower: x_i -= L[i][k] x_k, i > k; L[i][k] = M[cbase(k) + i]
+  // ---- forward, unit lower: x_i -= L[i][k] x_k, i > k; L[i][k] = M[cbase(k) + i] -------------------------------
+  {
+    double cur[U][SLOTS], nxt[U][SLOTS];
+    auto load_fwd = [&](double (&buf)[U][SLOTS], const int k0) {
 #pragma unroll
-  for (int k = 0; k < N - 1; ++k) {
-    const double xk = bcast_lane(x[k / 64], k % 64);
+      for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
-      if (64 * t + 63 > k) {
-        const double a = (lane + 64 * t > k && lane + 64 * t < N) ? M[SW::cbase(k) + rc[t]] : 0.0;
-        x[t] = fma(-a, xk, x[t]);
+        for (int t = 0; t < SLOTS; ++t) buf[u][t] = M[SW::cbase((k0 + u < N) ? k0 + u : N - 1) + rc[t]];
+    };
+    load_fwd(cur, 0);
+#pragma unroll
+    for (int k0 = 0; k0 < N - 1; k0 += U) {
+      if (k0 + U < N - 1) load_fwd(nxt, k0 + U);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u;
+        if (k < N - 1) {
+          const double xk = bcast_lane(x[k / 64], k % 64);
+#pragma unroll
+          for (int t = 0; t < SLOTS; ++t) {
+            if (64 * t + 63 > k) {
+              const double a = (lane + 64 * t > k && lane + 64 * t < N) ? cur[u][t] : 0.0;
+              x[t] = fma(-a, xk, x[t]);
+            }
+          }
+        }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) cur[u][t] = nxt[u][t];
     }
   }
 #pragma unroll
   for (int t = 0; t < SLOTS; ++t) x[t] *= M[cbr[t] + rc[t]];          // 1/d (pseudo-inverse rule folded in)
-  // backward with L^T: x_i -= L[k][i] x_k, i < k; L[k][i] = M[cbase(i) + k]: this lane's own columns
+  // ---- backward with L^T: x_i -= L[k][i] x_k, i < k; L[k][i] = M[cbase(i) + k]: this lane's own columns --------
+  {
+    double cur[U][SLOTS], nxt[U][SLOTS];
+    auto load_bwd = [&](double (&buf)[U][SLOTS], const int k0) {      // k = k0, k0 - 1, ...
 #pragma unroll
-  for (int k = N - 1; k >= 1; --k) {
-    const double xk = bcast_lane(x[k / 64], k % 64);
+      for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int t = 0; t < SLOTS; ++t) {
-      if (64 * t < k) {
-        const double a = (lane + 64 * t < k) ? M[cbr[t] + k] : 0.0;
-        x[t] = fma(-a, xk, x[t]);
+        for (int t = 0; t < SLOTS; ++t) buf[u][t] = M[cbr[t] + ((k0 - u >= 1) ? k0 - u : 1)];
+    };
+    load_bwd(cur, N - 1);
+#pragma unroll
+    for (int k0 = N - 1; k0 >= 1; k0 -= U) {
+      if (k0 - U >= 1) load_bwd(nxt, k0 - U);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 - u;
+        if (k >= 1) {
+          const double xk = bcast_lane(x[k / 64], k % 64);
+#pragma unroll
+          for (int t = 0; t < SLOTS; ++t) {
+            if (64 * t < k) {
+              const double a = (lane + 64 * t < k) ? cur[u][t] : 0.0;
+              x[t] = fma(-a, xk, x[t]);
+            }
+          }
+        }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) cur[u][t] = nxt[u][t];
     }
   }
 }
@@ -518,7 +597,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   const int ccomp = is_cone ? (pos & 3) : 0;
 
   const long long t_begin = wall_clock64();
-  long long ticks = 0, ph_asm = 0, ph_p3 = 0, ph_solve = 0, ph_p4 = 0;
+  long long ticks = 0, ph_asm = 0, ph_p3 = 0, ph_solve = 0, ph_p4 = 0, ph_wfac = 0;
   int flags = 0;
 
   // [-b; b_eq] (fcc_qp.cpp:149-150) into LDS, by wave 0; flag words cleared
@@ -572,7 +651,8 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       flags |= kFlagPresolveRan;
       const long long tw = wall_clock64();
       coop_factor_store<SH, WV>(L, lane, kPresolveMinPivot, Wt);
-      ticks += wall_clock64() - tw;
+      ph_wfac = wall_clock64() - tw;
+      ticks += ph_wfac;
       const bool wbad = iflags[1] != 0;
       if (wbad) {
         flags |= kFlagPresolveNumerical;
@@ -751,7 +831,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       a.phase_ticks[3 * B + inst] = ph_p3;
       a.phase_ticks[4 * B + inst] = ph_p4;
       a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
-      a.phase_ticks[6 * B + inst] = ph_asm;
+      a.phase_ticks[6 * B + inst] = ph_wfac;        // (of slot 1: the factorisation of W alone)
       a.phase_ticks[7 * B + inst] = t_begin;
     }
   }

@@ -19,4 +19,4 @@ ms = []
 for _ in range(6):
     s.solve_ok(*B.arrays()); ms.append(s.kernel_ms())
 print(sys.argv[1:], "kernel us %.1f" % (1e3 * np.median(ms[1:])), "phases us [load, factor, presolve, gram, admm, total]:",
-      ["%.1f" % (1e6 * v) for v in s.phase_seconds()[:6]], flush=True)
+      ["%.1f" % (1e6 * v) for v in s.phase_seconds()[:6]], "slot6 (coop: W factorisation) %.1f" % (1e6 * s.phase_seconds()[6]), flush=True)

@@ -32,6 +32,10 @@
 #pragma once
 #include "fccqp_fused_impl.h"
 
+#ifdef FCCQP_TICKET_DISPATCH
+#error "the ticketed block -> instance experiment (fccqp_device.h) draws its ticket in wave 0 only: not wired into the multi-wave cooperative kernel"
+#endif
+
 namespace fccqp {
 namespace coop {
 using namespace fused;

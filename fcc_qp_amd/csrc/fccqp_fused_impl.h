@@ -153,8 +153,15 @@ __device__ __forceinline__ double wave_max(double v) {
 // f_z == 0 exactly: Eigen's normalize() leaves the zero ray alone and the reference returns 0.
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
+#ifdef FCCQP_RCP_TWO_NEWTON
   r = fma(fma(-d, r, 1.0), r, r);
   r = fma(fma(-d, r, 1.0), r, r);
+#else
+  // one cubic step, r <- r (1 + e + e^2), e = 1 - d r: three dependent operations instead of the four of two
+  // Newton steps, on the critical path of every pivot of a diagonal tile (the raw v_rcp_f64 is good to ~1e-8)
+  const double e = fma(-d, r, 1.0);
+  r = fma(r, fma(e, e, e), r);
+#endif
   return r;
 }
 __device__ __forceinline__ double fast_rsqrt(double a) {  // a > 0

@@ -936,6 +936,11 @@ int fccqp_debug_phase_ticks(fccqp_solver *s, long long *out, long long count) {
   return FCCQP_OK;
 }
 
+int fccqp_debug_block_instance(int batch, int block) {
+  if (batch < 1 || block < 0 || block >= batch) return -1;
+  return (int)fccqp::permuted_index((unsigned)block, (unsigned)batch);
+}
+
 int fccqp_debug_read_workspace(fccqp_solver *s, double *out, long long count, long long *available) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   DeviceGuard g(s->device);

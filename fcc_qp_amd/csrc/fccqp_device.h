@@ -68,11 +68,22 @@ struct KernelArgs {
 // instance = order of arrival) was built and measured too: 0.394-0.397 on W-mix, no better than a static shuffle
 // (each XCD still runs exactly grid / 8 workgroups), and 1.2 % slower on W-sat (the atomic's round trip sits in
 // front of the first load).  Off by default.
-__device__ __forceinline__ unsigned mix_bits(unsigned x, const unsigned mask, const int half) {
+__host__ __device__ __forceinline__ unsigned mix_bits(unsigned x, const unsigned mask, const int half) {
   x ^= x >> half; x = (x * 0x9E3779B1u) & mask;
   x ^= x >> half; x = (x * 0x85EBCA77u) & mask;
   x ^= x >> half;
   return x;
+}
+// the permutation itself (also exported to the host tests as fccqp_debug_block_instance): t < batch
+__host__ __device__ __forceinline__ unsigned permuted_index(unsigned t, const unsigned batch) {
+  if (batch >= 128u) {                                     // (smaller launches are resident all at once)
+    int bits = 0;
+    while ((1u << bits) < batch) ++bits;                   // ceil(log2 batch), >= 7
+    const unsigned mask = (1u << bits) - 1u;
+    const int half = (bits + 1) >> 1;
+    do t = mix_bits(t, mask, half); while (t >= batch);    // cycle walking: expected < 2 rounds
+  }
+  return t;
 }
 __device__ __forceinline__ int block_instance(const KernelArgs &a) {
   unsigned t = blockIdx.x;
@@ -84,13 +95,7 @@ __device__ __forceinline__ int block_instance(const KernelArgs &a) {
 #endif
   const unsigned batch = (unsigned)a.batch;
   if (t >= batch) return -1;
-  if (batch >= 128u) {                                     // (smaller launches are resident all at once)
-    const int bits = 32 - __builtin_clz(batch - 1u);       // ceil(log2 batch), >= 7
-    const unsigned mask = (1u << bits) - 1u;
-    const int half = (bits + 1) >> 1;
-    do t = mix_bits(t, mask, half); while (t >= batch);    // cycle walking: expected < 2 rounds
-  }
-  return (int)t;
+  return (int)permuted_index(t, batch);
 }
 
 // ---- memory fences with their waits WRITTEN OUT ----------------------------------------------------------------

@@ -244,6 +244,12 @@ int fccqp_debug_phase_ticks(fccqp_solver *s, long long *out, long long count);
 int fccqp_algorithmic_bytes(const fccqp_solver *s, long long *bytes);
 
 /* ---- debugging aids ------------------------------------------------------------------------- */
+/* The block -> instance map of a batch launch (fccqp_device.h: a fixed pseudo-random bijection of blockIdx.x, so
+ * that a workload whose cost is periodic in the instance index does not load the XCDs / CUs unevenly): the instance
+ * that workgroup `block` of a launch of `batch` instances solves, or -1 if block >= batch.  Pure integer arithmetic,
+ * no device needed: the host tests check the bijection with it. */
+int fccqp_debug_block_instance(int batch, int block);
+
 /* Copies up to `count` doubles of the solver's global workspace to the host (the per-block KKT
  * factor of shapes too large for LDS, N > 198; the staged rho*G of the generic kernel's operator
  * iterations otherwise) and returns the number available in *available (0: no workspace).  Lets a

@@ -224,7 +224,10 @@ int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x,
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* Milliseconds the last solve's kernel(s) took on the device (hipEvent pair on the launch
- * stream); waits for the solve. */
+ * stream); waits for the solve.  Exception: a synchronous host-pointer solve of a small batch (staged
+ * inputs <= 1 MiB: the one-QP-per-tick path) records no events -- each costs ~5 us of stream time, a tenth
+ * of such a solve -- and reports the host-measured time from the launch to the completion of the device
+ * work instead (a few microseconds more than the kernel itself). */
 int fccqp_last_kernel_ms(fccqp_solver *s, float *ms);
 /* Mean device time (seconds) the instances of the last solve spent per phase (fused kernel; the generic
  * kernel fills the slots it has): out[0] issue of the matrix loads (assembly on the generic kernel),

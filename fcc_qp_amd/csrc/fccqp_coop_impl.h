@@ -409,7 +409,7 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
   lds_f64 *const Vbuf = L + SH::kBig + SH::kWfac;
   lds_f64 *const Sblk = L + SH::kSblk, *const Sinv = L + SH::kSinv, *const Srcp = L + SH::kSrcp;
   lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
-  // diagonal tile of panel Pn, by its owner: column 16 Pn + col of L (tile_ldl leaves T = -L), 1/d in the diagonal slots
+  // diagonal tile of panel Pn, by its owner: column 16 Pn + col of L (tile_ldl leaves T = L d), 1/d in the diagonal slots
   auto factor_diag = [&](auto pn) {
     constexpr int Pn = decltype(pn)::value;
     constexpr int kValid = (n - 16 * Pn < 16) ? n - 16 * Pn : 16;
@@ -422,7 +422,7 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
 #pragma unroll
       for (int i = 1; i < kValid; ++i) {
         lds_f64 *dst = (i > col) ? M + cb + 16 * Pn + i : Sblk + col;      // (above the diagonal: a dummy slot)
-        *dst = -T[i];
+        *dst = T[i] * rmine;
       }
     }
     if (bad && lane == 0) iflags[1] = 1;

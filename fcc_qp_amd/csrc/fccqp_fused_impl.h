@@ -540,50 +540,88 @@ template <int K>
 __device__ __forceinline__ void dpp_fma(double &y, const double l, const double f) {
   asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(y) : "v"(l), "v"(f), "n"(K));
 }
-// Elimination step K of the diagonal tile: column c (this lane) takes  S_ic -= S_iK (S_Kc / d_K), i > K, for
-// c > K; the pivot of step K+1 is broadcast and inverted right after the first update (look-ahead).
-template <int K, int I>
+// Lane masks that depend only on the column c = lane & 15 are compile-time constants (the tile is replicated in the
+// four 16-lane rows of the wave): an SGPR-pair literal instead of a v_cmp per use, whose results the compiler used
+// to hoist out of the sixteen steps and then spill to VGPR lanes.
+__host__ __device__ constexpr unsigned long long rows4(const unsigned m16) { return (m16 & 0xffffull) * 0x0001000100010001ull; }
+template <int K> struct ColMask {
+  static constexpr unsigned long long eq = rows4(1u << K), gt = rows4(0xffffu << (K + 1));
+};
+__device__ __forceinline__ double select_lanes(const unsigned long long mask, const double if_set, const double if_clear) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(if_clear)), "v"(__double2loint(if_set)), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(if_clear)), "v"(__double2hiint(if_set)), "s"(mask));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double select_lanes_or_zero(const unsigned long long mask, const double if_set) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(if_set)), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(if_set)), "s"(mask));
+  return __hiloint2double(hi, lo);
+}
+// lane K of this lane's 16-lane row, one instruction; volatile: it DPP-reads a register a volatile FMA has just written
+// and must keep its place behind it (2 wait states, see tile_ldl)
+template <int K>
+__device__ __forceinline__ double row_bcast_ordered(const double &v) {
+  double d;
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(v), "n"(K));
+  return d;
+}
+// -(a / d) with the rounding of pivot_quotient (negations are exact and ride on the source modifiers)
+__device__ __forceinline__ double neg_pivot_quotient(const double a, const double d, const double r) {
+  const double nq = -a * r;
+  return fma(-fma(d, nq, a), r, nq);
+}
+// rows I = LO .. HI of column K of L^-1's recursion: Y_I += S_IK (lane K) * f, f = -Y_K / d_K
+template <int K, int LO, int HI>
+__device__ __forceinline__ void tile_inverse_rows(double (&Y)[16], const double (&T)[16], const double f) {
+  if constexpr (LO <= HI) {
+    dpp_fma<K>(Y[LO], T[LO], f);
+    tile_inverse_rows<K, LO + 1, HI>(Y, T, f);
+  }
+}
+// Elimination step K of the diagonal tile, d = d_K in every lane.  Column c (this lane) takes
+// S_ic -= S_iK (S_Kc / d_K), i > K, for c > K (lanes c <= K add zero), and -- WITH_INVERSE -- the rows below K of L^-1
+// take column K's contribution in the same step: y_i -= l_iK y_K with l_iK d_K = S_iK read from lane K, whose column is
+// final since step K - 1, and the 1/d_K folded into the other factor (no separate scaling pass over the tile).
+// Order inside a step (the FMAs are volatile asm and keep it): the update of row K + 1 first, then the L^-1 rows that
+// do not touch it, then the broadcast of the next pivot out of it (VALU write -> DPP read: two wait states, s_nop
+// where a step has no such work left), L^-1's row K + 1 and the remaining rows.  The pivot chain
+// (rcp, refinement, quotient, selects) stays in one piece in front of the DPP block: spreading its links between the
+// FMAs to cover their latency was measured 1.2 % SLOWER per solve -- the wave is issue-bound and alternating DPP and
+// plain fp64 operations costs more than the dependent issue does.
+template <int K, int LO, int HI>
 __device__ __forceinline__ void tile_step_rows(double (&T)[16], const double negm) {
-  if constexpr (I < 16) {
-    dpp_self_fma<K>(T[I], negm);
-    tile_step_rows<K, I + 1>(T, negm);
+  if constexpr (LO <= HI) {
+    dpp_self_fma<K>(T[LO], negm);
+    tile_step_rows<K, LO + 1, HI>(T, negm);
   }
 }
-template <int K>
-__device__ __forceinline__ void tile_steps(double (&T)[16], double d, double rinv, double &rmine, const int c) {
-  if constexpr (K < 16) {
-    rmine = (c == K) ? rinv : rmine;
-    if constexpr (K < 15) {
-      const double negm = (c > K) ? -pivot_quotient(T[K], d, rinv) : 0.0;
-      // steps 12 .. 14 have fewer than two other updates between the write of T[i] by step K-1 and its
-      // DPP read here
-      if constexpr (K >= 12) asm volatile("s_nop 1" : "+v"(T[K + 1]));
-      dpp_self_fma<K>(T[K + 1], negm);
-      asm volatile("s_nop 1" : "+v"(T[K + 1]));        // VALU write -> DPP read of the next pivot
-      const double dn = row_bcast<K + 1>(T[K + 1]);
-      const double rn = pivot_inverse(dn);
-      tile_step_rows<K, K + 2>(T, negm);
-      tile_steps<K + 1>(T, dn, rn, rmine, c);
+// (NV valid rows: the padding rows / columns NV .. 15 of a factorisation's last tile are the identity -- no step for
+// them, and no update of them: their entries in the columns being eliminated are zero)
+template <int K, bool WITH_INVERSE, int NV>
+__device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], const double d, double &rmine) {
+  const double r = pivot_inverse(d);
+  rmine = select_lanes(ColMask<K>::eq, r, rmine);
+  if constexpr (K + 1 < NV) {
+    const double negm = select_lanes_or_zero(ColMask<K>::gt, neg_pivot_quotient(T[K], d, r));
+    dpp_self_fma<K>(T[K + 1], negm);
+    double f = 0.0;
+    if constexpr (WITH_INVERSE) {
+      f = -r * Y[K];
+      tile_inverse_rows<K, K + 2, NV - 1>(Y, T, f);
     }
-  }
-}
-template <int K, int I>
-__device__ __forceinline__ void tile_inverse_rows(double (&Y)[16], const double (&Ls)[16]) {
-  if constexpr (I < 16) {
-    dpp_fma<K>(Y[I], Ls[I], Y[K]);
-    tile_inverse_rows<K, I + 1>(Y, Ls);
-  }
-}
-template <int K>
-__device__ __forceinline__ void tile_inverse_steps(double (&Y)[16], const double (&Ls)[16]) {
-  if constexpr (K < 15) {
-    tile_inverse_rows<K, K + 1>(Y, Ls);
-    tile_inverse_steps<K + 1>(Y, Ls);
+    if constexpr (!WITH_INVERSE || K + 3 >= NV) asm volatile("s_nop 1" : "+v"(T[K + 1]));
+    const double dn = row_bcast_ordered<K + 1>(T[K + 1]);
+    if constexpr (WITH_INVERSE) dpp_fma<K>(Y[K + 1], T[K + 1], f);
+    tile_step_rows<K, K + 2, NV - 1>(T, negm);
+    tile_steps<K + 1, WITH_INVERSE, NV>(T, Y, dn, rmine);
   }
 }
 // Diagonal tile, column-per-lane (every 16-lane row of the wave holds a copy and does the same work):
 // in  T[i] = S[i][c], the symmetric 16 x 16 block;
-// out rmine = 1/d_c (pseudo-inverse rule: 0 for |d_c| <= DBL_MIN), Y[i] = (L^-1)[i][c] for i > c (Y[c] = 1,
+// out rmine = 1/d_c (pseudo-inverse rule: 0 for |d_c| <= DBL_MIN), T[i] = l_ic d_c for i > c (the column of L still
+//     times its pivot: a caller that stores L multiplies by rmine), Y[i] = (L^-1)[i][c] for i > c (Y[c] = 1,
 //     Y[i < c] = 0).  MAX_RCP: the largest reciprocal pivot still accepted (a definite matrix whose pivots
 //     must stay above 1 / MAX_RCP), or 0: then only a dropped or non-finite pivot (rmine 0 or NaN: d was
 //     zero, subnormal, infinite or NaN) is reported.  Padding rows are identity.
@@ -592,23 +630,20 @@ template <int NVALID, bool WITH_INVERSE = true>
 __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], double &rmine, const int c,
                                          const double max_rcp = 0.0) {
   rmine = 1.0;
+  if constexpr (WITH_INVERSE) {
+    const int one_hi = __double2hiint(1.0);
+    static_for<0, 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      int hi;
+      asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(one_hi), "s"(ColMask<i>::eq));
+      Y[i] = __hiloint2double(hi, 0);
+    });
+  }
   const double d0 = row_bcast<0>(T[0]);
-  tile_steps<0>(T, d0, pivot_inverse(d0), rmine, c);
+  tile_steps<0, WITH_INVERSE, NVALID>(T, Y, d0, rmine);
   // judged once per tile: lane c holds 1/d_c
   const bool lane_bad = (max_rcp > 0.0) ? !(rmine > 0.0 && rmine < max_rcp) : __builtin_amdgcn_class(rmine, 0x3 | 0x20 | 0x40);
-  const bool bad = __any((c < NVALID) && lane_bad);
-  // lane c now holds S_ic^(c) = l_ic d_c for i > c.  L^-1 by columns: y_i -= l_iK y_K, K < i, with l_iK fetched
-  // from lane K (negated and scaled here, once)
-  // (in place: T becomes -L)
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    T[i] = -(T[i] * rmine);
-    Y[i] = (i == c) ? 1.0 : 0.0;
-  }
-  asm volatile("s_nop 1" : "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]), "+v"(T[8]));
-  asm volatile("s_nop 1" : "+v"(T[9]), "+v"(T[10]), "+v"(T[11]), "+v"(T[12]), "+v"(T[13]), "+v"(T[14]), "+v"(T[15]));
-  if constexpr (WITH_INVERSE) tile_inverse_steps<0>(Y, T);
-  return bad;
+  return __any((c < NVALID) && lane_bad);
 }
 
 // P0: the upper triangle of K_rho = [[Q + rho I, A^T],[A, 0]] (fcc_qp.cpp:146-150,62-64) from global memory
@@ -834,7 +869,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
           for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
           Srcp[col] = rmine;
         }
-        // column 16 P + col of L (tile_ldl left T = -L), its d and 1/d
+        // column 16 P + col of L (tile_ldl left T = L d), its 1/d
         if (col < kValid) {
           const int jcol = 16 * P + col, cb = SW::cbase(jcol);
           M[cb + jcol] = rmine;
@@ -843,7 +878,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
 #pragma unroll
           for (int i = 1; i < kValid; ++i) {
             lds_f64 *dst = (i > col) ? M + cb + 16 * P + i : Sblk + col;
-            *dst = -T[i];
+            *dst = T[i] * rmine;
           }
         }
       }

@@ -175,7 +175,7 @@ __device__ __forceinline__ d4 tile_fetch(const lds_f64 *buf, const int lane) {
 }
 
 // diagonal tile of a panel: the owner factorises it and leaves L^-1 (strictly lower part) and 1/d in the exchange area
-template <int kValid, bool WITH_INVERSE>
+template <int kValid, bool WITH_INVERSE, bool KEEP_L>
 __device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &Cpp, double (&T)[16], double &rmine, const double max_rcp,
                                           const int slot) {
   const int col = lane & 15, grp = lane >> 4;
@@ -192,7 +192,7 @@ __device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &
     T[2 * ip + 1] = t.y;
   }
   lds_fence();
-  const bool bad = tile_ldl<kValid, WITH_INVERSE>(T, Y, rmine, col, max_rcp);
+  const bool bad = tile_ldl<kValid, WITH_INVERSE, KEEP_L>(T, Y, rmine, col, max_rcp);
   if (lane < 16) {
     if constexpr (WITH_INVERSE) {
       lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
@@ -232,7 +232,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     constexpr int Pn = decltype(pn)::value;
     constexpr int kValid = (N - 16 * Pn < 16) ? N - 16 * Pn : 16;
     double T[16], rmine;
-    const bool bad = diag_tile<kValid, true>(L, lane, C[Pn][Pn], T, rmine, 0.0, Pn & 1);
+    const bool bad = diag_tile<kValid, true, false>(L, lane, C[Pn][Pn], T, rmine, 0.0, Pn & 1);
     if (lane < 16) L[SH::kRcp + 16 * Pn + col] = rmine;
     if (bad && lane == 0) iflags[0] = 1;
   };
@@ -415,7 +415,7 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
     constexpr int kValid = (n - 16 * Pn < 16) ? n - 16 * Pn : 16;
     constexpr bool kLast = (Pn + 1 == NW);
     double T[16], rmine;
-    const bool bad = diag_tile<kValid, !kLast>(L, lane, C[Pn][Pn], T, rmine, 1.0 / min_pivot, Pn & 1);
+    const bool bad = diag_tile<kValid, !kLast, true>(L, lane, C[Pn][Pn], T, rmine, 1.0 / min_pivot, Pn & 1);
     if (lane < 16 && col < kValid) {
       const int jcol = 16 * Pn + col, cb = SW::cbase(jcol);
       M[cb + jcol] = rmine;

@@ -101,8 +101,27 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {  // src_l
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double max2(double a, double b) { return (a < b) ? b : a; }  // std::max
-__device__ __forceinline__ double min2(double a, double b) { return (b < a) ? b : a; }  // std::min
+// Selects on 64-bit values, written out as VOP3-encoded v_cndmask_b32 with the lane mask in an SGPR pair.  Left to
+// itself the compiler turns a compare with one user into v_cmp -> VCC and the VOP2 form `v_cndmask_b32_e32 ..., vcc`,
+// and on gfx950 that form costs a lone wave 19 cycles an instruction where every other VALU instruction -- the VOP3
+// form with the very same VCC as its mask included -- costs 5 to 7 (tools/issue_probe.hip).
+__device__ __forceinline__ double select_lanes(const unsigned long long mask, const double if_set, const double if_clear) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(if_clear)), "v"(__double2loint(if_set)), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(if_clear)), "v"(__double2hiint(if_set)), "s"(mask));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double select_lanes_or_zero(const unsigned long long mask, const double if_set) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(if_set)), "s"(mask));
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(if_set)), "s"(mask));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double select64(const bool c, const double if_true, const double if_false) {
+  return select_lanes(__builtin_amdgcn_ballot_w64(c), if_true, if_false);
+}
+__device__ __forceinline__ double max2(double a, double b) { return select64(a < b, b, a); }  // std::max
+__device__ __forceinline__ double min2(double a, double b) { return select64(b < a, b, a); }  // std::min
 
 // ---- DPP wave reductions (no LDS traffic).  gfx9 DPP controls: quad_perm 0x00..0xff,
 // row_half_mirror 0x141, row_mirror 0x140, row_bcast15 0x142, row_bcast31 0x143 ----------------
@@ -202,7 +221,7 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
 
 __device__ __forceinline__ double pivot_inverse(double dd) {   // Eigen's LDLT::solve drops |d| <= DBL_MIN
   const double r = fast_rcp(dd);
-  return (fabs(dd) > DBL_MIN) ? r : 0.0;
+  return select_lanes_or_zero(__builtin_amdgcn_ballot_w64(fabs(dd) > DBL_MIN), r);
 }
 // a / d from r = pivot_inverse(d): the product a r corrected by one residual step, i.e. the correctly rounded
 // quotient in all but rare cases and EXACTLY 1 for a == d.  That is what makes a duplicated equality row
@@ -547,18 +566,6 @@ __host__ __device__ constexpr unsigned long long rows4(const unsigned m16) { ret
 template <int K> struct ColMask {
   static constexpr unsigned long long eq = rows4(1u << K), gt = rows4(0xffffu << (K + 1));
 };
-__device__ __forceinline__ double select_lanes(const unsigned long long mask, const double if_set, const double if_clear) {
-  int lo, hi;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(if_clear)), "v"(__double2loint(if_set)), "s"(mask));
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(if_clear)), "v"(__double2hiint(if_set)), "s"(mask));
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double select_lanes_or_zero(const unsigned long long mask, const double if_set) {
-  int lo, hi;
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(if_set)), "s"(mask));
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(if_set)), "s"(mask));
-  return __hiloint2double(hi, lo);
-}
 // lane K of this lane's 16-lane row, one instruction; volatile: it DPP-reads a register a volatile FMA has just written
 // and must keep its place behind it (2 wait states, see tile_ldl)
 template <int K>
@@ -599,34 +606,41 @@ __device__ __forceinline__ void tile_step_rows(double (&T)[16], const double neg
 }
 // (NV valid rows: the padding rows / columns NV .. 15 of a factorisation's last tile are the identity -- no step for
 // them, and no update of them: their entries in the columns being eliminated are zero)
-template <int K, bool WITH_INVERSE, int NV>
+// KEEP_L = false (the caller does not read T afterwards): the multiplier is NOT masked to the columns right of K.
+// Lane c <= K then "updates" its own, finished column with a multiplier of its own -- lane K's is -S_KK / d_K = -1,
+// which zeroes that column -- and nobody minds: L^-1 has read lane K's column by then (its row K + 1 moves in front
+// of the first update for that), the pivots come from columns right of K only, and two v_cndmask + two s_mov per
+// step are gone.
+template <int K, bool WITH_INVERSE, int NV, bool KEEP_L>
 __device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], const double d, double &rmine) {
   const double r = pivot_inverse(d);
   rmine = select_lanes(ColMask<K>::eq, r, rmine);
   if constexpr (K + 1 < NV) {
-    const double negm = select_lanes_or_zero(ColMask<K>::gt, neg_pivot_quotient(T[K], d, r));
-    dpp_self_fma<K>(T[K + 1], negm);
+    const double nq = neg_pivot_quotient(T[K], d, r);
+    const double negm = KEEP_L ? select_lanes_or_zero(ColMask<K>::gt, nq) : nq;
     double f = 0.0;
     if constexpr (WITH_INVERSE) {
       f = -r * Y[K];
-      tile_inverse_rows<K, K + 2, NV - 1>(Y, T, f);
+      if constexpr (!KEEP_L) dpp_fma<K>(Y[K + 1], T[K + 1], f);
     }
+    dpp_self_fma<K>(T[K + 1], negm);
+    if constexpr (WITH_INVERSE) tile_inverse_rows<K, K + 2, NV - 1>(Y, T, f);
     if constexpr (!WITH_INVERSE || K + 3 >= NV) asm volatile("s_nop 1" : "+v"(T[K + 1]));
     const double dn = row_bcast_ordered<K + 1>(T[K + 1]);
-    if constexpr (WITH_INVERSE) dpp_fma<K>(Y[K + 1], T[K + 1], f);
+    if constexpr (WITH_INVERSE && KEEP_L) dpp_fma<K>(Y[K + 1], T[K + 1], f);
     tile_step_rows<K, K + 2, NV - 1>(T, negm);
-    tile_steps<K + 1, WITH_INVERSE, NV>(T, Y, dn, rmine);
+    tile_steps<K + 1, WITH_INVERSE, NV, KEEP_L>(T, Y, dn, rmine);
   }
 }
 // Diagonal tile, column-per-lane (every 16-lane row of the wave holds a copy and does the same work):
 // in  T[i] = S[i][c], the symmetric 16 x 16 block;
-// out rmine = 1/d_c (pseudo-inverse rule: 0 for |d_c| <= DBL_MIN), T[i] = l_ic d_c for i > c (the column of L still
-//     times its pivot: a caller that stores L multiplies by rmine), Y[i] = (L^-1)[i][c] for i > c (Y[c] = 1,
+// out rmine = 1/d_c (pseudo-inverse rule: 0 for |d_c| <= DBL_MIN), KEEP_L: T[i] = l_ic d_c for i > c (the column of L
+//     still times its pivot: a caller that stores L multiplies by rmine; without KEEP_L T is scratch), Y[i] = (L^-1)[i][c] for i > c (Y[c] = 1,
 //     Y[i < c] = 0).  MAX_RCP: the largest reciprocal pivot still accepted (a definite matrix whose pivots
 //     must stay above 1 / MAX_RCP), or 0: then only a dropped or non-finite pivot (rmine 0 or NaN: d was
 //     zero, subnormal, infinite or NaN) is reported.  Padding rows are identity.
 // (WITH_INVERSE = false: the last tile of a factorisation without right-hand sides -- nothing is solved with it)
-template <int NVALID, bool WITH_INVERSE = true>
+template <int NVALID, bool WITH_INVERSE = true, bool KEEP_L = false>
 __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], double &rmine, const int c,
                                          const double max_rcp = 0.0) {
   rmine = 1.0;
@@ -640,7 +654,7 @@ __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], doubl
     });
   }
   const double d0 = row_bcast<0>(T[0]);
-  tile_steps<0, WITH_INVERSE, NVALID>(T, Y, d0, rmine);
+  tile_steps<0, WITH_INVERSE, NVALID, KEEP_L>(T, Y, d0, rmine);
   // judged once per tile: lane c holds 1/d_c
   const bool lane_bad = (max_rcp > 0.0) ? !(rmine > 0.0 && rmine < max_rcp) : __builtin_amdgcn_class(rmine, 0x3 | 0x20 | 0x40);
   return __any((c < NVALID) && lane_bad);
@@ -861,7 +875,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
       }
       lds_fence();
       constexpr bool kLast = (P + 1 == NW);
-      FCCQP_FINE(0, (bad |= tile_ldl<kValid, !kLast>(T, Y, rmine, col, 1.0 / min_pivot)));
+      FCCQP_FINE(0, (bad |= tile_ldl<kValid, !kLast, true>(T, Y, rmine, col, 1.0 / min_pivot)));
       if (lane < 16) {
         if constexpr (!kLast) {
           lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
@@ -1148,7 +1162,6 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
   // lane, read back by v_readlane on every iteration
   int max_iter = a.max_iter;
   asm volatile("" : "+s"(max_iter));
-  n_iter = max_iter;           // :78
   // x = x_c + (rho G) w   == the KKT solve of :83-87, this lane = row `var` of rho G.  Every lane needs all
   // of w.  Reading it back as LDS broadcasts (ds_read_b128 of two doubles into all 64 lanes: a
   // 1-KiB return per instruction) made the four waves of a CU wait on the LDS return path: 409 ns
@@ -1160,9 +1173,12 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
   // test, which then runs in the shadow of the LDS round trip (the wave's only one per iteration).
   constexpr int NQ = (n + 15) / 16;
   double Wq[NQ];
+  // (lane masks of the loop as 64-bit scalars: the selects and the exit test below take them as SGPR pairs)
+  const unsigned long long var_lanes = __builtin_amdgcn_ballot_w64(var_i != 0), cone_lanes = __builtin_amdgcn_ballot_w64(cone_i != 0);
   auto exchange_w = [&]() {
-    // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
-    const double w = (cone_i != 0) ? (lcbar - mulc) : (xbar - mux);
+    // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82); both differences, then
+    // one select (the compiler's own choice was to select both operands first: one instruction more)
+    const double w = select_lanes(cone_lanes, lcbar - mulc, xbar - mux);
     *wslot = w;
     lds_fence();     // (one wave: its LDS operations complete in order; this is a compiler fence)
 #pragma unroll
@@ -1173,50 +1189,57 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
   // parts of it in AGPRs -- and then reads them back with v_accvgpr_read on EVERY iteration of the loop
   // (seen once: 38.5 -> 44.7 us for the loop after an unrelated change upstream)
   pin_vgprs<0>(Mrow);
-  if (max_iter > 0) exchange_w();
-  // (the build aligns loop headers to 256 bytes, -falign-loops: the time per iteration moved by 5 % with
-  // nothing but the placement of this -- otherwise identical -- loop in the code)
+  double xc_v = xc;            // likewise x_c, the start of the mat-vec's accumulator
+  asm volatile("" : "+v"(xc_v));
+  n_iter = max_iter;           // :78
+  if (max_iter > 0) {
+    exchange_w();
+    // (the build aligns loop headers to 256 bytes, -falign-loops: the time per iteration moved by 5 % with
+    // nothing but the placement of this -- otherwise identical -- loop in the code)
+    int iter = 0, bound;
 #pragma nounroll
-  for (int iter = 0; iter < max_iter; ++iter) {
-    double acc[kMvAcc] = {xc, 0.0, 0.0, 0.0};
-    // the DPP read of a VGPR needs two wait states after a VALU write of it (the registers come
-    // straight from the LDS reads, but a copy could be scheduled in between): pin them here
-    if constexpr (NQ == 4) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]), "+v"(Wq[3]));
-    else if constexpr (NQ == 3) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]));
-    else if constexpr (NQ == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
-    else asm volatile("s_nop 1" : "+v"(Wq[0]));
-    dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
-    x = mv_total(acc);
-    // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in lanes 4c .. 4c+2 of
-    // this lane's quad: three quad_perm broadcasts (v_mov_b32 DPP pairs), no LDS round trip
-    const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused
-    const double cfx = quad_bcast<0>(xm), cfy = quad_bcast<1>(xm), cfz = quad_bcast<2>(xm);
-    // Every lane runs both updates, unmasked (a select per state variable per iteration otherwise).  A
-    // lane without a variable has x = mu_x = 0 and infinite bounds: it stays at zero.  Outside the
-    // contacts lcbar / lr / mulc are garbage that nothing reads: w, the exit test, the reported norms
-    // and the write-back all select on the lane's kind.
-    {
-      const double v = x + mux;
-      const double tt = min2(v, vub);   // std::min(x(i), ub(i))   constraint_utils.cpp:43
-      xbar = max2(tt, vlb);             // std::max(., lb(i))
-      xr = x - xbar;                    // :95
-      mux += xr;                        // :101
-    }
-    {
-      lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_i != 0);
-      lr = x - lcbar;                   // :96
-      mulc += lr;                       // :102
-    }
-    exchange_w();                       // for the next iteration (harmless after the last)
-    // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test
-    // is one ballot instead of two wave reductions; the norms themselves (:97-98) are only
-    // reported, and are reduced once after the loop.  An empty contact set has norm 0.
-    // (bitwise, not short-circuit: lane masks combined with scalar instructions, no branches)
-    const bool fail = ((var_i != 0) & !(fabs(xr) < eps_b)) | ((cone_i != 0) & !(fabs(lr) < eps_f));
-    if (__builtin_amdgcn_ballot_w64(fail) == 0) {
-      n_iter = iter;
-      break;
-    }
+    do {
+      double acc[kMvAcc] = {xc_v, 0.0, 0.0, 0.0};
+      // (the DPP read of a VGPR needs two wait states after a VALU write of it.  Wq comes straight from the LDS
+      // reads and the s_waitcnt sits in between; tests/test_code_objects.py fails on a build where the
+      // compiler puts a copy there.  An `s_nop 1` pinned here used to cost 16 cycles per iteration.)
+      dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
+      x = mv_total(acc);
+      // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in lanes 4c .. 4c+2 of
+      // this lane's quad: three quad_perm broadcasts (v_mov_b32 DPP pairs), no LDS round trip
+      const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused
+      const double cfx = quad_bcast<0>(xm), cfy = quad_bcast<1>(xm), cfz = quad_bcast<2>(xm);
+      // Every lane runs both updates, unmasked (a select per state variable per iteration otherwise).  A
+      // lane without a variable has x = mu_x = 0 and infinite bounds: it stays at zero.  Outside the
+      // contacts lcbar / lr / mulc are garbage that nothing reads: w, the exit test, the reported norms
+      // and the write-back all select on the lane's kind.
+      {
+        const double v = x + mux;
+        const double tt = min2(v, vub);   // std::min(x(i), ub(i))   constraint_utils.cpp:43
+        xbar = max2(tt, vlb);             // std::max(., lb(i))
+        xr = x - xbar;                    // :95
+        mux += xr;                        // :101
+      }
+      {
+        lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_i != 0);
+        lr = x - lcbar;                   // :96
+        mulc += lr;                       // :102
+      }
+      exchange_w();                       // for the next iteration (harmless after the last)
+      // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test is two compares
+      // whose lane masks meet in scalar registers (s_and / s_or set SCC for the branch: no VALU instruction makes
+      // a boolean out of them) instead of two wave reductions; the norms themselves (:97-98) are only reported,
+      // and are reduced once after the loop.  An empty contact set has norm 0.  n_iter: the index of the
+      // iteration that passed the test, or max_iter.
+      const unsigned long long fail = (var_lanes & __builtin_amdgcn_ballot_w64(!(fabs(xr) < eps_b))) |
+                                      (cone_lanes & __builtin_amdgcn_ballot_w64(!(fabs(lr) < eps_f)));
+      // one exit: a converged iteration is not counted and drops the bound to zero.  Written out, because the
+      // backend turns every formulation of "break, or count and compare" into the same twelve SALU instructions
+      // (each one an issue slot of this lone wave like any other instruction); these are three plus the compare
+      asm volatile("s_cmp_lg_u64 %2, 0\n\ts_cselect_b32 %1, %3, 0\n\ts_addc_u32 %0, %0, 0"
+                   : "+s"(iter), "=&s"(bound) : "s"(fail), "s"(max_iter) : "scc");
+    } while (iter < bound);
+    n_iter = iter;
   }
   if (a.max_iter > 0) {
     // :97-98  abs(max(maxCoeff, -minCoeff)) == max_i |r_i| of the last iteration executed

@@ -709,9 +709,10 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   int n_iter = max_iter;                             // :78
   double Wq[NQL];
   wg_barrier();                                      // everyone has x (and is done with the factor of W): the exchange area is free
+  const unsigned long long var_lanes = __builtin_amdgcn_ballot_w64(isvar), cone_lanes = __builtin_amdgcn_ballot_w64(is_cone);
   auto publish_w = [&]() {
     // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
-    const double w = is_cone ? (lcbar - mulc) : (xbar - mux);
+    const double w = select_lanes(cone_lanes, lcbar - mulc, xbar - mux);
     if (RH == 1 || c == 0) *wslot = w;
   };
   auto fetch_w = [&]() {
@@ -727,10 +728,8 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
 #pragma nounroll
   for (int iter = 0; iter < max_iter; ++iter) {
     double acc[kMvAcc] = {0.0, 0.0, 0.0, 0.0};
-    if constexpr (NQL == 4) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]), "+v"(Wq[3]));
-    else if constexpr (NQL == 3) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]), "+v"(Wq[2]));
-    else if constexpr (NQL == 2) asm volatile("s_nop 1" : "+v"(Wq[0]), "+v"(Wq[1]));
-    else asm volatile("s_nop 1" : "+v"(Wq[0]));
+    // (Wq comes straight from the LDS reads, an s_waitcnt in between: no VALU write in front of the DPP reads;
+    // tests/test_code_objects.py checks the built code for that)
     dpp_matvec<0, ncol, NQL>(acc, Wq, Mrow);
     if constexpr (CS > 1) {
       // (double-buffered by iteration parity: a wave may write the next partial sums while a slower one still
@@ -760,8 +759,8 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     }
     publish_w();
     // exit test :105-109 (see the one-wave kernel): one ballot per row half
-    const bool fail = (isvar & !(fabs(xr) < eps_b)) | (is_cone & !(fabs(lr) < eps_f));
-    const bool half_fails = __builtin_amdgcn_ballot_w64(fail) != 0;
+    const bool half_fails = ((var_lanes & __builtin_amdgcn_ballot_w64(!(fabs(xr) < eps_b))) |
+                             (cone_lanes & __builtin_amdgcn_ballot_w64(!(fabs(lr) < eps_f)))) != 0;
     bool any_fails = half_fails;
     if constexpr (RH == 1) {
       lds_fence();                                   // (w went to this wave's own copy)

@@ -77,11 +77,16 @@ __host__ __device__ __forceinline__ unsigned mix_bits(unsigned x, const unsigned
 // the permutation itself (also exported to the host tests as fccqp_debug_block_instance): t < batch
 __host__ __device__ __forceinline__ unsigned permuted_index(unsigned t, const unsigned batch) {
   if (batch >= 128u) {                                     // (smaller launches are resident all at once)
-    int bits = 0;
-    while ((1u << bits) < batch) ++bits;                   // ceil(log2 batch), >= 7
+    const int bits = 32 - __builtin_clz(batch - 1u);       // ceil(log2 batch), >= 7
     const unsigned mask = (1u << bits) - 1u;
     const int half = (bits + 1) >> 1;
-    do t = mix_bits(t, mask, half); while (t >= batch);    // cycle walking: expected < 2 rounds
+    // cycle walking, expected < 2 rounds.  The first round stands outside the loop: the kernels are built with every
+    // loop header aligned to 256 bytes, and the padding in front of a loop on the way into the kernel is ~50 s_nop
+    // that a lone wave pays 6 cycles each for
+    t = mix_bits(t, mask, half);
+    if (__builtin_expect(t >= batch, 0)) {
+      do t = mix_bits(t, mask, half); while (t >= batch);
+    }
   }
   return t;
 }

@@ -509,17 +509,23 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
   const bool isvar = grow >= 0;
   const int lr = isvar ? grow : 0;
   xc = isvar ? vbuf[lr] : 0.0;
-  if constexpr (n % 2 == 0) {
-    const lds_d2 *g2 = reinterpret_cast<const lds_d2 *>(M + lr * n);
+  // (a lane without a variable reads a row of zeros laid over the reciprocal pivots, which are in registers by now:
+  // one select of the row address instead of two per entry of the row)
+  static_assert(SH::KKT::kRowsPadded >= n, "room for a zero row behind the image");
+  if (lane < n) M[SH::kRcpOffset + lane] = 0.0;
+  lds_fence();
+  const lds_f64 *const rowp = isvar ? M + lr * n : M + SH::kRcpOffset;
+  if constexpr (n % 2 == 0 && SH::kRcpOffset % 2 == 0) {
+    const lds_d2 *g2 = reinterpret_cast<const lds_d2 *>(rowp);
 #pragma unroll
     for (int jp = 0; jp < n / 2; ++jp) {
       const d2 g = g2[jp];
-      Mrow[2 * jp] = isvar ? g.x : 0.0;
-      Mrow[2 * jp + 1] = isvar ? g.y : 0.0;
+      Mrow[2 * jp] = g.x;
+      Mrow[2 * jp + 1] = g.y;
     }
   } else {
 #pragma unroll
-    for (int jj = 0; jj < n; ++jj) Mrow[jj] = isvar ? M[lr * n + jj] : 0.0;
+    for (int jj = 0; jj < n; ++jj) Mrow[jj] = rowp[jj];
   }
   lds_fence();
   return bad;
@@ -611,13 +617,17 @@ __device__ __forceinline__ void tile_step_rows(double (&T)[16], const double neg
 // which zeroes that column -- and nobody minds: L^-1 has read lane K's column by then (its row K + 1 moves in front
 // of the first update for that), the pivots come from columns right of K only, and two v_cndmask + two s_mov per
 // step are gone.
+// (eqm / gtm: the lane masks "column == K" and "column > K" of the step, carried from step to step in SGPR pairs --
+// one s_lshl_b64 / s_andn2_b64 each instead of two s_mov_b32 literals per mask and step; tile_ldl hides the first
+// pair from constant folding)
 template <int K, bool WITH_INVERSE, int NV, bool KEEP_L>
-__device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], const double d, double &rmine) {
+__device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], const double d, double &rmine,
+                                           const unsigned long long eqm, const unsigned long long gtm) {
   const double r = pivot_inverse(d);
-  rmine = select_lanes(ColMask<K>::eq, r, rmine);
+  rmine = select_lanes(eqm, r, rmine);
   if constexpr (K + 1 < NV) {
     const double nq = neg_pivot_quotient(T[K], d, r);
-    const double negm = KEEP_L ? select_lanes_or_zero(ColMask<K>::gt, nq) : nq;
+    const double negm = KEEP_L ? select_lanes_or_zero(gtm, nq) : nq;
     double f = 0.0;
     if constexpr (WITH_INVERSE) {
       f = -r * Y[K];
@@ -629,7 +639,8 @@ __device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], con
     const double dn = row_bcast_ordered<K + 1>(T[K + 1]);
     if constexpr (WITH_INVERSE && KEEP_L) dpp_fma<K>(Y[K + 1], T[K + 1], f);
     tile_step_rows<K, K + 2, NV - 1>(T, negm);
-    tile_steps<K + 1, WITH_INVERSE, NV, KEEP_L>(T, Y, dn, rmine);
+    const unsigned long long eqn = eqm << 1;
+    tile_steps<K + 1, WITH_INVERSE, NV, KEEP_L>(T, Y, dn, rmine, eqn, KEEP_L ? (gtm & ~eqn) : 0ull);
   }
 }
 // Diagonal tile, column-per-lane (every 16-lane row of the wave holds a copy and does the same work):
@@ -654,7 +665,9 @@ __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], doubl
     });
   }
   const double d0 = row_bcast<0>(T[0]);
-  tile_steps<0, WITH_INVERSE, NVALID, KEEP_L>(T, Y, d0, rmine);
+  unsigned long long eq0 = ColMask<0>::eq, gt0 = ColMask<0>::gt;
+  asm volatile("" : "+s"(eq0), "+s"(gt0));
+  tile_steps<0, WITH_INVERSE, NVALID, KEEP_L>(T, Y, d0, rmine, eq0, gt0);
   // judged once per tile: lane c holds 1/d_c
   const bool lane_bad = (max_rcp > 0.0) ? !(rmine > 0.0 && rmine < max_rcp) : __builtin_amdgcn_class(rmine, 0x3 | 0x20 | 0x40);
   return __any((c < NVALID) && lane_bad);
@@ -809,12 +822,20 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       if (!zero_tile(P, cb)) {
-        if (P == kfirst(cb)) X[P][cb] = x_initial(P, cb);
-        d4 t = X[P][cb];
+        if (cb == P && cb != cbd) {
+          // the tile of the unit columns 16 P .. 16 P + 15 is still the identity when its panel comes up (the
+          // panels above it only had zero tiles in this column block): L^-1 I is the tile tile_ldl has just
+          // left in the exchange area -- four LDS reads instead of four MFMAs
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (16 * P + 4 * r < N) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], X[P][cb][r], t, 0, 0, 0);
-        X[P][cb] = t;
+          for (int r = 0; r < 4; ++r) X[P][cb][r] = Sinv[16 * col + grp + 4 * r];
+        } else {
+          if (P == kfirst(cb)) X[P][cb] = x_initial(P, cb);
+          d4 t = X[P][cb];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * P + 4 * r < N) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], X[P][cb][r], t, 0, 0, 0);
+          X[P][cb] = t;
+        }
       }
     }
     // (3) the rows below

@@ -185,14 +185,7 @@ __device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &
   lds_fence();
   double Y[16];
   const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
-#pragma unroll
-  for (int ip = 0; ip < 8; ++ip) {
-    const d2 t = colp[ip];
-    T[2 * ip] = t.x;
-    T[2 * ip + 1] = t.y;
-  }
-  lds_fence();
-  const bool bad = tile_ldl<kValid, WITH_INVERSE, KEEP_L>(T, Y, rmine, col, max_rcp);
+  const bool bad = tile_ldl<kValid, WITH_INVERSE, KEEP_L>(T, Y, rmine, col, colp, max_rcp);
   if (lane < 16) {
     if constexpr (WITH_INVERSE) {
       lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);

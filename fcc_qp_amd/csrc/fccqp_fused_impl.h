@@ -214,7 +214,7 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
   const bool inside = mu * fz >= nxy;                   // :10-12
   const bool polar = fz < -mu * nxy;                    // :15-17
   const double t = fma(mu, nxy, fz) * kc;               // :20-23, see above
-  const double dir = is_z ? 1.0 : rs * v;
+  const double dir = select64(is_z, 1.0, rs * v);       // (VOP3 select: the loop-invariant mask otherwise sits in VCC for the 19-cycle VOP2 form)
   const double side = (fz == 0.0) ? 0.0 : t * dir;      // zero ray: Eigen's normalize() no-op -> 0
   return inside ? v : (polar ? 0.0 : side);
 }
@@ -620,10 +620,10 @@ __device__ __forceinline__ void tile_step_rows(double (&T)[16], const double neg
 // (eqm / gtm: the lane masks "column == K" and "column > K" of the step, carried from step to step in SGPR pairs --
 // one s_lshl_b64 / s_andn2_b64 each instead of two s_mov_b32 literals per mask and step; tile_ldl hides the first
 // pair from constant folding)
-template <int K, bool WITH_INVERSE, int NV, bool KEEP_L>
+template <int K, bool WITH_INVERSE, int NV, bool KEEP_L, bool RULE>
 __device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], const double d, double &rmine,
                                            const unsigned long long eqm, const unsigned long long gtm) {
-  const double r = pivot_inverse(d);
+  const double r = RULE ? pivot_inverse(d) : fast_rcp(d);
   rmine = select_lanes(eqm, r, rmine);
   if constexpr (K + 1 < NV) {
     const double nq = neg_pivot_quotient(T[K], d, r);
@@ -640,7 +640,7 @@ __device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], con
     if constexpr (WITH_INVERSE && KEEP_L) dpp_fma<K>(Y[K + 1], T[K + 1], f);
     tile_step_rows<K, K + 2, NV - 1>(T, negm);
     const unsigned long long eqn = eqm << 1;
-    tile_steps<K + 1, WITH_INVERSE, NV, KEEP_L>(T, Y, dn, rmine, eqn, KEEP_L ? (gtm & ~eqn) : 0ull);
+    tile_steps<K + 1, WITH_INVERSE, NV, KEEP_L, RULE>(T, Y, dn, rmine, eqn, KEEP_L ? (gtm & ~eqn) : 0ull);
   }
 }
 // Diagonal tile, column-per-lane (every 16-lane row of the wave holds a copy and does the same work):
@@ -651,9 +651,21 @@ __device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], con
 //     must stay above 1 / MAX_RCP), or 0: then only a dropped or non-finite pivot (rmine 0 or NaN: d was
 //     zero, subnormal, infinite or NaN) is reported.  Padding rows are identity.
 // (WITH_INVERSE = false: the last tile of a factorisation without right-hand sides -- nothing is solved with it)
-template <int NVALID, bool WITH_INVERSE = true, bool KEEP_L = false>
-__device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], double &rmine, const int c,
-                                         const double max_rcp = 0.0) {
+// (The tile arrives through LDS -- `colp`: this lane's column, written in accumulator layout by the caller -- and is run
+// OPTIMISTICALLY first: without the |d| <= DBL_MIN test and its two selects in each of the sixteen steps.  A pivot that
+// the rule would have dropped shows in its reciprocal (|1/d| >= 2^1022, infinite or NaN, which is also what a zero
+// or subnormal d gives); then -- rank-deficient equality rows, practically never otherwise -- the column is read
+// again and the tile redone with the rule in every step.  Conservative: a pivot within an ulp of DBL_MIN may take
+// the second pass and come out the same.)
+template <int NVALID, bool WITH_INVERSE, bool KEEP_L, bool RULE>
+__device__ __forceinline__ void tile_run(double (&T)[16], double (&Y)[16], double &rmine, const lds_d2 *colp) {
+#pragma unroll
+  for (int ip = 0; ip < 8; ++ip) {
+    const d2 t = colp[ip];
+    T[2 * ip] = t.x;
+    T[2 * ip + 1] = t.y;
+  }
+  lds_fence();
   rmine = 1.0;
   if constexpr (WITH_INVERSE) {
     const int one_hi = __double2hiint(1.0);
@@ -667,7 +679,14 @@ __device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], doubl
   const double d0 = row_bcast<0>(T[0]);
   unsigned long long eq0 = ColMask<0>::eq, gt0 = ColMask<0>::gt;
   asm volatile("" : "+s"(eq0), "+s"(gt0));
-  tile_steps<0, WITH_INVERSE, NVALID, KEEP_L>(T, Y, d0, rmine, eq0, gt0);
+  tile_steps<0, WITH_INVERSE, NVALID, KEEP_L, RULE>(T, Y, d0, rmine, eq0, gt0);
+}
+template <int NVALID, bool WITH_INVERSE = true, bool KEEP_L = false>
+__device__ __forceinline__ bool tile_ldl(double (&T)[16], double (&Y)[16], double &rmine, const int c, const lds_d2 *colp,
+                                         const double max_rcp = 0.0) {
+  tile_run<NVALID, WITH_INVERSE, KEEP_L, false>(T, Y, rmine, colp);
+  if (__builtin_expect(__any((c < NVALID) && !(fabs(rmine) < 0x1p1022)), 0))
+    tile_run<NVALID, WITH_INVERSE, KEEP_L, true>(T, Y, rmine, colp);
   // judged once per tile: lane c holds 1/d_c
   const bool lane_bad = (max_rcp > 0.0) ? !(rmine > 0.0 && rmine < max_rcp) : __builtin_amdgcn_class(rmine, 0x3 | 0x20 | 0x40);
   return __any((c < NVALID) && lane_bad);
@@ -785,14 +804,7 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
     {
       double T[16], Y[16], rmine;
       const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
-#pragma unroll
-      for (int ip = 0; ip < 8; ++ip) {
-        const d2 t = colp[ip];
-        T[2 * ip] = t.x;
-        T[2 * ip + 1] = t.y;
-      }
-      lds_fence();
-      FCCQP_FINE(0, bad |= tile_ldl<kValid>(T, Y, rmine, col));
+      FCCQP_FINE(0, bad |= tile_ldl<kValid>(T, Y, rmine, col, colp));
       if (lane < 16) {
         lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
 #pragma unroll
@@ -888,15 +900,8 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
     {
       double T[16], Y[16], rmine;
       const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
-#pragma unroll
-      for (int ip = 0; ip < 8; ++ip) {
-        const d2 t = colp[ip];
-        T[2 * ip] = t.x;
-        T[2 * ip + 1] = t.y;
-      }
-      lds_fence();
       constexpr bool kLast = (P + 1 == NW);
-      FCCQP_FINE(0, (bad |= tile_ldl<kValid, !kLast, true>(T, Y, rmine, col, 1.0 / min_pivot)));
+      FCCQP_FINE(0, (bad |= tile_ldl<kValid, !kLast, true>(T, Y, rmine, col, colp, 1.0 / min_pivot)));
       if (lane < 16) {
         if constexpr (!kLast) {
           lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);

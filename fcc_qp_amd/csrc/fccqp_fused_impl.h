@@ -285,8 +285,9 @@ struct Shape : Packed<N_VARS + N_EQ> {
   // LDS staging of the border columns (kBorder x kTileRows, behind the reciprocal pivots) and, later, of
   // the Gram columns n .. n + kBorder (rows 0 .. n + kBorder)
   static constexpr int kBorderOffset = kRcpOffset + KKT::kRowsPadded;
+  // (the Gram columns are stored by whole row blocks: 16 (n / 16 + 1) rows)
   static constexpr int kBorderDoubles =
-      (kBorder * kTileRows > (n + kBorder + 1) * (kBorder + 1)) ? kBorder * kTileRows : (n + kBorder + 1) * (kBorder + 1);
+      (kBorder * kTileRows > 16 * (n / 16 + 1) * (kBorder + 1)) ? kBorder * kTileRows : 16 * (n / 16 + 1) * (kBorder + 1);
   // LDS carve (doubles): work area M[kMat] | vbuf[max(kNp, 64)].  M holds, in turn: the exchange scratch,
   // 1/d and the border staging during the factorisation; the rho G image; the packed factor of W and its
   // exchange scratch.  (The matrix itself never is in LDS: it lives in registers.)
@@ -379,12 +380,16 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
   double x2[NB > 0 ? NB : 1];
   lds_f64 *const Eb = M + SH::kBorderOffset;     // Eb[row * (NB + 1) + k] = P[row][n + k]
   if constexpr (NB > 0) {
+    // (one lane predicate around all the stores -- the columns n .. n + NB of the product -- and every row of the
+    // NI row blocks stored, the ones past n + NB into padding: a predicate per store costs an EXEC round trip each)
+    static_assert(SH::kBorderDoubles >= 16 * NI * (NB + 1), "Eb holds whole row blocks");
+    {
+      const int cc = 16 * cbd + col;
+      if (cc >= n && cc <= n + NB) {
 #pragma unroll
-    for (int I = 0; I < NI; ++I) {
+        for (int I = 0; I < NI; ++I)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + grp + 4 * r, c = 16 * cbd + col;
-        if (c >= n && c <= n + NB && row <= n + NB) Eb[row * (NB + 1) + (c - n)] = Gt[I][cbd][r];
+          for (int r = 0; r < 4; ++r) Eb[(16 * I + grp + 4 * r) * (NB + 1) + (cc - n)] = Gt[I][cbd][r];
       }
     }
     lds_fence();
@@ -439,6 +444,9 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
         else Sinv[i][cI] = y[i];
       }
     }
+    constexpr int kDummyStride = 16 * NI + 1;          // (odd: the sixteen columns spread over the LDS banks)
+    static_assert(kDummyStride * 15 + 16 * NI <= SH::kRcpOffset, "the dummy slots lie in the dead image / exchange area");
+    lds_f64 *const xc_base = (16 * cbd + col == n) ? vbuf : M + kDummyStride * col;    // (a slot of its own for every lane)
 #pragma unroll
     for (int I = 0; I < NI; ++I) {
 #pragma unroll
@@ -446,7 +454,7 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
         const int row = 16 * I + grp + 4 * r;
         double zr[NB];
 #pragma unroll
-        for (int aa = 0; aa < NB; ++aa) zr[aa] = Eb[((row <= n + NB) ? row : 0) * (NB + 1) + 1 + aa];
+        for (int aa = 0; aa < NB; ++aa) zr[aa] = Eb[row * (NB + 1) + 1 + aa];
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) {
           double acc = 0.0;
@@ -454,13 +462,14 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
           for (int aa = 0; aa < NB; ++aa) acc += zr[aa] * Sinv[aa][bb];
           corr_r[I][r][bb] = acc;
         }
-        // x_c for the lanes that hold column n of the product
-        if (16 * cbd + col == n && row < n) {
-          double v = Gt[I][cbd][r];
+        // x_c (column n of the product, corrected): every lane computes it, the lanes that hold column n store it --
+        // the others to the dead head of the work area, which the rho G image overwrites next (one select of the
+        // base address for all sixteen stores instead of an EXEC round trip around each)
+        double v = Gt[I][cbd][r];
 #pragma unroll
-          for (int aa = 0; aa < NB; ++aa) v -= zr[aa] * x2[aa];
-          vbuf[row] = v;
-        }
+        for (int aa = 0; aa < NB; ++aa) v -= zr[aa] * x2[aa];
+        if (16 * I + 4 * r + 3 < n) xc_base[row] = v;                     // (whole group of four rows below n)
+        else if (16 * I + 4 * r < n) { if (row < n) xc_base[row] = v; }
       }
     }
   }
@@ -475,26 +484,37 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
 #pragma unroll
         for (int bb = 0; bb < NB; ++bb) zc[bb] = Eb[((c < n) ? c : 0) * (NB + 1) + 1 + bb];
       }
-      // (a tile that lies wholly inside the n x n block needs no masks: I and J are constants here)
+      // (a tile that lies wholly inside the n x n block needs no masks: I and J are constants here; an edge tile
+      // computes its four values first and stores them under ONE column predicate, the row condition decided at
+      // compile time wherever a whole group of four rows lies on one side of n)
       const bool interior = (16 * I + 15 < n) && (16 * J + 15 < n);
+      const int c = 16 * J + col;
+      double g4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + grp + 4 * r, c = 16 * J + col;     // Gt[I][J][r] = (K1^-1)[row][c]
+        const int row = 16 * I + grp + 4 * r;                        // Gt[I][J][r] = (K1^-1)[row][c]
         double gv = Gt[I][J][r];
         if constexpr (NB > 0) {
 #pragma unroll
           for (int bb = 0; bb < NB; ++bb) gv = fma(corr_r[I][r][bb], zc[bb], gv);
         }
-        const double g = rho * gv;
+        g4[r] = rho * gv;
         const bool inside = interior || (row < n && c < n);
-        if (inside) {
-          M[row * n + c] = g;
-          if (J != I) M[c * n + row] = g;                            // the mirror tile
-        }
         if (NB == 0 && J == cbd && c == n && row < n) vbuf[row] = Gt[I][J][r];     // x_c
         if (J < NW) {
           const double unit = (I == J && row == c) ? 1.0 : 0.0;
-          Wt[I][J][r] = inside ? unit - g : unit;
+          Wt[I][J][r] = inside ? unit - g4[r] : unit;
+        }
+      }
+      if (interior || c < n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + grp + 4 * r;
+          const bool rows_in = interior || (16 * I + 4 * r + 3 < n), rows_out = !interior && (16 * I + 4 * r >= n);
+          if (rows_in || (!rows_out && row < n)) {
+            M[row * n + c] = g4[r];
+            if (J != I) M[c * n + row] = g4[r];                      // the mirror tile
+          }
         }
       }
     }

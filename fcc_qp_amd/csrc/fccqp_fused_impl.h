@@ -249,6 +249,7 @@ struct Packed {
   // cbase(j + 1) - cbase(j): lets loops walk the columns with one scalar add
   static constexpr int cstep(int j) { return N - j - 1 + (((j & 1) == (N & 1)) ? 1 : 0); }
   static constexpr int kPacked = (cstart(N) + 1) & ~1;
+  static constexpr bool kZeroFilled = false;
   // exchange scratch of the diagonal tiles (tile_factor_forward, tile_factor_store): the tile, its inverse,
   // 16 reciprocal pivots (+ padding)
   static constexpr int kScratch = 544;
@@ -256,12 +257,27 @@ struct Packed {
   static constexpr int kNp = (N + 1) & ~1;
 };
 
+// The factor of W = I - rho G as the presolve's two sweeps want it: a full NN x NN square, column-major with an odd
+// column stride (a lane walking along its own column -- the backward sweep -- then hits all LDS banks), L strictly
+// below the diagonal and ZEROS on and above it, so that a sweep step multiplies by the entry it loads without a
+// "row below the pivot?" select, and the reciprocal pivots in NN slots behind the square.  Element (i, j), i > j,
+// at cbase(j) + i as in Packed.
+template <int NN>
+struct ZeroFilledSquare {
+  static constexpr int N = NN;
+  static constexpr bool kZeroFilled = true;
+  static constexpr int kStride = NN | 1;
+  static constexpr int cbase(int j) { return j * kStride; }
+  static constexpr int kDinv = (NN * kStride + 1) & ~1;
+  static constexpr int kPacked = (kDinv + NN + 1) & ~1;
+};
+
 template <int N_VARS, int N_EQ, int NC, int LC_START>
 struct Shape : Packed<N_VARS + N_EQ> {
   using KKT = Packed<N_VARS + N_EQ>;
   using KKT::N; using KKT::kNp;
   // the packed n x n factor of W = I - rho G for the presolve's two sweeps (see fused_kernel)
-  using Reduced = Packed<N_VARS>;
+  using Reduced = ZeroFilledSquare<N_VARS>;
   static constexpr int n = N_VARS, m = N_EQ, nc = NC, s = LC_START;
   static_assert(n >= 1 && n < kWave, "one lane per variable plus one lane for the rhs column");
   static_assert(m >= 0 && m <= kWave, "one lane per equality row when the right-hand side is staged");
@@ -909,6 +925,16 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
   lds_f64 *const Sblk = M + kOff;
   lds_f64 *const Sinv = Sblk + 256;
   lds_f64 *const Srcp = Sblk + 512;
+  if constexpr (SW::kZeroFilled) {
+    // zeros on and above the diagonal of the square: the whole of it first (the rho G image it lies over is in
+    // registers by now), L then goes on top
+    static_assert(SW::kDinv % 2 == 0 && SW::kDinv <= kOff, "the square ends in front of the exchange scratch");
+    lds_d2 *const z2 = reinterpret_cast<lds_d2 *>(M);
+#pragma unroll
+    for (int k = 0; k < (SW::kDinv / 2 + kWave - 1) / kWave; ++k)
+      if ((k + 1) * kWave <= SW::kDinv / 2 || k * kWave + lane < SW::kDinv / 2) z2[k * kWave + lane] = d2{0.0, 0.0};
+    lds_fence();
+  }
   bool bad = false;
   static_for<0, NW>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
@@ -932,7 +958,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
         // column 16 P + col of L (tile_ldl left T = L d), its 1/d
         if (col < kValid) {
           const int jcol = 16 * P + col, cb = SW::cbase(jcol);
-          M[cb + jcol] = rmine;
+          M[SW::kZeroFilled ? SW::kDinv + jcol : cb + jcol] = rmine;
           // (entries above the diagonal go to a per-lane dummy slot of the dead exchange tile: one select
           // of the address instead of an exec-mask round trip per store)
 #pragma unroll
@@ -987,6 +1013,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
 template <class SH>
 __device__ __forceinline__ void solve_lds_one_slot(const lds_f64 *M, const int lane, double &x) {
   constexpr int N = SH::N, U = 8;
+  constexpr bool kZ = SH::kZeroFilled;       // zeros on and above the diagonal: no "row below the pivot?" selects
   static_assert(N <= kWave, "one row per lane");
   const int row = lane;
   const int rc = (row < N) ? row : N - 1;        // clamped: in-bounds reads for idle lanes
@@ -1005,16 +1032,19 @@ __device__ __forceinline__ void solve_lds_one_slot(const lds_f64 *M, const int l
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = k0 + u;
-        const double a = (row > k && k < N) ? cur[u] : 0.0;
-        const double xk = bcast_lane(x, (k < N) ? k : 0);
-        x = fma(-a, xk, x);
+        if (k < N - 1) {                           // (column N - 1 has nothing below its diagonal)
+          const double a = kZ ? cur[u] : ((row > k) ? cur[u] : 0.0);
+          const double xk = bcast_lane(x, k);
+          x = fma(-a, xk, x);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
   }
-  // ---- D^-1: the diagonal slot holds 1/d with Eigen's pseudo-inverse rule folded in -----------------------
-  x *= M[cbr + rc];
+  // ---- D^-1: 1/d with Eigen's pseudo-inverse rule folded in (the diagonal slot of the packed layout) ---------
+  if constexpr (kZ) x *= M[SH::kDinv + rc];
+  else x *= M[cbr + rc];
   // ---- backward with L^T: x_i -= L[k][i] x_k, i < k.  L[k][row] = M[cbase(row) + k]: this lane's own column ---
   {
     double cur[U], nxt[U];
@@ -1029,9 +1059,11 @@ __device__ __forceinline__ void solve_lds_one_slot(const lds_f64 *M, const int l
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = k0 - u;
-        const double a = (k >= 1 && row < k) ? cur[u] : 0.0;
-        const double xk = bcast_lane(x, (k >= 1) ? k : 1);
-        x = fma(-a, xk, x);
+        if (k >= 1) {
+          const double a = kZ ? cur[u] : ((row < k) ? cur[u] : 0.0);
+          const double xk = bcast_lane(x, k);
+          x = fma(-a, xk, x);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) cur[u] = nxt[u];

@@ -666,6 +666,13 @@ __device__ __forceinline__ void tile_steps(double (&T)[16], double (&Y)[16], con
     const double negm = KEEP_L ? select_lanes_or_zero(gtm, nq) : nq;
     double f = 0.0;
     if constexpr (WITH_INVERSE) {
+      // the unit entry of row K of L^-1 goes in now, with the mask of this step (Y starts as all zeros: lane K of
+      // Y[K] has only ever accumulated multiples of the zeros right of the diagonal in the rows above)
+      {
+        int hi;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(Y[K])), "v"(__double2hiint(1.0)), "s"(eqm));
+        Y[K] = __hiloint2double(hi, __double2loint(Y[K]));
+      }
       f = -r * Y[K];
       if constexpr (!KEEP_L) dpp_fma<K>(Y[K + 1], T[K + 1], f);
     }
@@ -704,11 +711,14 @@ __device__ __forceinline__ void tile_run(double (&T)[16], double (&Y)[16], doubl
   lds_fence();
   rmine = 1.0;
   if constexpr (WITH_INVERSE) {
-    const int one_hi = __double2hiint(1.0);
-    static_for<0, 16>([&](auto ic) {
+    // Y = 0; the unit diagonal arrives row by row in the steps (rows NVALID - 1 .. 15, which no step reaches as
+    // "row K", here)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Y[i] = 0.0;
+    static_for<(NVALID > 0 ? NVALID - 1 : 0), 16>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       int hi;
-      asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(one_hi), "s"(ColMask<i>::eq));
+      asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(1.0)), "s"(ColMask<i>::eq));
       Y[i] = __hiloint2double(hi, 0);
     });
   }

@@ -60,11 +60,16 @@ struct Shape {
   static constexpr int cbd = n / 16;                 // the block that holds the dense column r = [-b; b_eq]
   static constexpr int NW = (n + 15) / 16;           // row / column blocks of G and W
   static constexpr int RH = (n + 63) / 64;           // row halves of the ADMM phase
-  static constexpr int CS = W / RH;                  // column splits of the mat-vec
+  static constexpr int CS = W / RH;                  // waves per row half
+  // column splits of the ADMM mat-vec: at most one ADMM wave per SIMD.  Every wave of a row half repeats that half's
+  // projections, exchange and exit test (~65 instructions against 114 / CS FMAs), and two waves on one SIMD only
+  // take turns at its issue slots: with eight waves the loop ran 1460 cycles per iteration, issue-bound on
+  // redundant work.  The waves beyond RH * CSA leave the kernel in front of the loop.
+  static constexpr int CSA = (RH * CS > 4) ? ((4 / RH > 1) ? 4 / RH : 1) : CS;
   static constexpr int kPos = 64 * RH;               // lane positions (one per variable, some unused)
   static_assert(n >= 1 && n <= 128 && m >= 1, "two row halves at most");
   static_assert(W == 2 || W == 4 || W == 8, "waves per workgroup");
-  static_assert(W % RH == 0 && CS >= 1 && CS <= NW, "every column split owns at least one 16-column block");
+  static_assert(W % RH == 0 && CS >= 1 && CSA >= 1 && CSA <= CS && CSA <= NW, "every column split owns at least one 16-column block");
   static_assert(nc % 3 == 0 && nc > 0 && s + nc <= n, "fcc_qp.cpp:32-33; shapes without contacts run on the generic kernel");
   static constexpr int kContacts = nc / 3;
   static_assert(4 * kContacts <= kPos, "one quad of lanes per contact");
@@ -72,7 +77,7 @@ struct Shape {
   static constexpr int ownC(int J) { return J % W; }
   static constexpr int ownX(int cb) { return cb % W; }
   // column split c of the mat-vec owns the 16-column blocks [qlo(c), qlo(c + 1))
-  static constexpr int qlo(int c) { return (NW * c) / CS; }
+  static constexpr int qlo(int c) { return (NW * c) / CSA; }
   // position (row half * 64 + lane) -> variable: contact c in positions 4c .. 4c+2, the other variables in the
   // fourth position of those quads, then behind the contacts, in increasing order; -1: no variable
   __device__ static __forceinline__ int pos_variable(const int pos) {
@@ -612,7 +617,8 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     if (lane < 16) iflags[lane] = 0;
   }
 
-  constexpr int q0 = SH::qlo(c), q1 = SH::qlo(c + 1);
+  constexpr bool kAdmmWave = c < SH::CSA;            // (the others: q0 / q1 are placeholders, nothing is read)
+  constexpr int q0 = kAdmmWave ? SH::qlo(c) : 0, q1 = kAdmmWave ? SH::qlo(c + 1) : 1;
   constexpr int col0 = 16 * q0, ncol = ((16 * q1 < n) ? 16 * q1 : n) - col0, NQL = q1 - q0;
   double Mrow[ncol];
   double xc = 0.0, x = 0.0;
@@ -637,8 +643,10 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     {
       const lds_f64 *img = L + SH::kBig;
       xc = isvar ? rhs[vi] : 0.0;
+      if constexpr (kAdmmWave) {
 #pragma unroll
-      for (int j = 0; j < ncol; ++j) Mrow[j] = isvar ? img[vi * n + col0 + j] : 0.0;
+        for (int j = 0; j < ncol; ++j) Mrow[j] = isvar ? img[vi * n + col0 + j] : 0.0;
+      }
     }
     if (a.warm_start) x = isvar ? xs[vi] : 0.0;       // fcc_qp.cpp:136-139
     wg_barrier();                                     // the image is dead: the factor of W goes over it
@@ -682,6 +690,9 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   }
 
   // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------------------------------
+  // (a wave without a column split is done: s_barrier counts the surviving waves of the workgroup only)
+  if constexpr (!kAdmmWave) return;
+  constexpr int CSA = SH::CSA;
   lds_f64 *const part = L + SH::kBig + SH::kPart;
   lds_f64 *const wv = L + SH::kBig + SH::kWvOff + ((RH == 1) ? WV : 0) * SH::kWv;
   lds_i32 *const exitw = iflags + 4;                 // [2][RH]
@@ -724,7 +735,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     // (Wq comes straight from the LDS reads, an s_waitcnt in between: no VALU write in front of the DPP reads;
     // tests/test_code_objects.py checks the built code for that)
     dpp_matvec<0, ncol, NQL>(acc, Wq, Mrow);
-    if constexpr (CS > 1) {
+    if constexpr (CSA > 1) {
       // (double-buffered by iteration parity: a wave may write the next partial sums while a slower one still
       // reads these; the barrier of the next iteration separates it from the one after)
       lds_f64 *const pp = part + (iter & 1) * CS * SH::kPos;
@@ -732,7 +743,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       wg_barrier();
       x = xc;
 #pragma unroll
-      for (int cc = 0; cc < CS; ++cc) x += pp[cc * SH::kPos + pos];
+      for (int cc = 0; cc < CSA; ++cc) x += pp[cc * SH::kPos + pos];
     } else {
       x = xc + mv_total(acc);
     }

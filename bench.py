@@ -82,8 +82,8 @@ KERNEL_NAMES = {1: "generic", 2: "fused", 3: "fused_split", 4: "coop"}
 def fused_mfma_count(n, m):
     """v_mfma_f64_16x16x4 instructions the one-wave fused kernel executes per QP: (K_rho factorisation + forward
     solve, Gram product, factorisation of W) -- the loop bounds of tile_factor_forward / gram_output /
-    tile_factor_store in fcc_qp_amd/csrc/fccqp_fused_impl.h restated (walking shape: 468 + 196 + 64 = 728, the count
-    in the shipped code object)."""
+    tile_factor_store in fcc_qp_amd/csrc/fccqp_fused_impl.h restated (walking shape: 456 + 196 + 64 = 716, the count
+    in the shipped code object, not counting the second pass of a diagonal tile's column, which holds none)."""
     N = n + m
     border = N % 16 if (N % 16 != 0 and N - N % 16 >= n and (n % 16) + (N % 16) <= 15 and N % 16 <= 3) else 0
     N1 = N - border
@@ -94,7 +94,9 @@ def fused_mfma_count(n, m):
     for P in range(NRB):
         ks = sum(1 for r in range(4) if 16 * P + 4 * r < N1)
         live = sum(1 for cb in range(NCB) if not zero_tile(P, cb))
-        f += ks * ((NRB - P - 1) + live)
+        # (the tile of unit columns 16 P .. 16 P + 15 is still the identity when panel P solves it: L^-1 is read from LDS)
+        solved = live - (1 if (P < NCB and P != cbd) else 0)
+        f += ks * ((NRB - P - 1) + solved)
         for I in range(P + 1, NRB):
             f += ks * ((NRB - I) + live)
     for I in range(cbd + 1 if border else NW):

@@ -22,7 +22,8 @@
 //   Pw  presolve x0 = W^-1 x_c (Woodbury, as in the one-wave kernel): W factorised by the same panel scheme, its
 //       factor written packed to LDS, the two triangular sweeps by wave 0 (two rows per lane for n > 64).
 //   P4  ADMM iterations.  Rows (variables) live in lanes, 64 per "row half" (RH = 1 or 2 halves), the columns of
-//       rho G are split over CS = W / RH waves per half: every wave holds a 64 x (n / CS) block of rho G in
+//       rho G are split over CSA = min(W / RH, 4 / RH) waves per half (one ADMM wave per SIMD; the others have left
+//       the kernel by then): every wave holds a 64 x (n / CSA) block of rho G in
 //       registers, forms its partial mat-vec with DPP-fed FMAs, the partial sums meet in LDS (barrier), and every
 //       wave of a half repeats the (cheap) projections for that half's rows, so only w crosses waves again
 //       (second barrier, not needed when RH == 1).

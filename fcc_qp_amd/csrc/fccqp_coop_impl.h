@@ -714,7 +714,8 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   int n_iter = max_iter;                             // :78
   double Wq[NQL];
   wg_barrier();                                      // everyone has x (and is done with the factor of W): the exchange area is free
-  const unsigned long long var_lanes = __builtin_amdgcn_ballot_w64(isvar), cone_lanes = __builtin_amdgcn_ballot_w64(is_cone);
+  const unsigned long long var_lanes = __builtin_amdgcn_ballot_w64(isvar), cone_lanes = __builtin_amdgcn_ballot_w64(is_cone),
+                           z_lanes = __builtin_amdgcn_ballot_w64(ccomp == 2);
   auto publish_w = [&]() {
     // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82)
     const double w = select_lanes(cone_lanes, lcbar - mulc, xbar - mux);
@@ -758,7 +759,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       mux += xr;                        // :101
     }
     {
-      lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, ccomp == 2);
+      lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_lanes);
       lr = x - lcbar;                   // :96
       mulc += lr;                       // :102
     }

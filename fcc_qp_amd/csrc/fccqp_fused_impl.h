@@ -205,7 +205,7 @@ __device__ __forceinline__ double cone_lane_constant(double mu, bool is_z) {
   return is_z ? c : mu * c;
 }
 __device__ __forceinline__ double project_cone_component(double fx, double fy, double fz, double mu, double kc,
-                                                         double v, bool is_z) {
+                                                         double v, const unsigned long long z_lanes) {
   const double nxy2 = fx * fx + fy * fy;
   // f_xy == 0 (inside if mu f_z >= 0, else the origin): the clamp keeps the rsqrt finite, and then
   // nxy = 0 * rs = 0 and dir = rs * 0 = 0 exactly, with no select
@@ -214,9 +214,12 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
   const bool inside = mu * fz >= nxy;                   // :10-12
   const bool polar = fz < -mu * nxy;                    // :15-17
   const double t = fma(mu, nxy, fz) * kc;               // :20-23, see above
-  const double dir = select64(is_z, 1.0, rs * v);       // (VOP3 select: the loop-invariant mask otherwise sits in VCC for the 19-cycle VOP2 form)
-  const double side = (fz == 0.0) ? 0.0 : t * dir;      // zero ray: Eigen's normalize() no-op -> 0
-  return inside ? v : (polar ? 0.0 : side);
+  const double dir = select_lanes(z_lanes, 1.0, rs * v);   // (VOP3 select on the loop-invariant lane mask of the z components)
+  // zero ray (f_z == 0): Eigen's normalize() no-op -> 0, like the polar cone.  Straight-line VOP3 selects: whether the
+  // backend makes this a branch around the outside-the-cone work or two VOP2 selects on VCC changed from build to build
+  const unsigned long long keep = __builtin_amdgcn_ballot_w64(fz != 0.0) & __builtin_amdgcn_ballot_w64(!polar);
+  const double outside = select_lanes_or_zero(keep, t * dir);
+  return select64(inside, v, outside);
 }
 
 __device__ __forceinline__ double pivot_inverse(double dd) {   // Eigen's LDLT::solve drops |d| <= DBL_MIN
@@ -1262,7 +1265,8 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
   constexpr int NQ = (n + 15) / 16;
   double Wq[NQ];
   // (lane masks of the loop as 64-bit scalars: the selects and the exit test below take them as SGPR pairs)
-  const unsigned long long var_lanes = __builtin_amdgcn_ballot_w64(var_i != 0), cone_lanes = __builtin_amdgcn_ballot_w64(cone_i != 0);
+  const unsigned long long var_lanes = __builtin_amdgcn_ballot_w64(var_i != 0), cone_lanes = __builtin_amdgcn_ballot_w64(cone_i != 0),
+                           z_lanes = __builtin_amdgcn_ballot_w64(z_i != 0);
   auto exchange_w = [&]() {
     // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82); both differences, then
     // one select (the compiler's own choice was to select both operands first: one instruction more)
@@ -1309,7 +1313,7 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
         mux += xr;                        // :101
       }
       {
-        lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_i != 0);
+        lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_lanes);
         lr = x - lcbar;                   // :96
         mulc += lr;                       // :102
       }

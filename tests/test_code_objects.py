@@ -216,3 +216,25 @@ def test_agent_fences_carry_their_store_waits(objects):
                     n_acq += 1
                     assert wait_after(body, i), f"{name}: acquire at {i}: no s_waitcnt vmcnt(0) before the next memory instruction"
     assert n_rel >= 8 and n_acq >= 8, (n_rel, n_acq)
+
+
+def test_admm_loop_has_no_vop2_selects(objects):
+    """`v_cndmask_b32_e32` (VOP2, implicit VCC) costs a lone wave 19 cycles where the VOP3 form costs 6 (tools/issue_probe.hip,
+    DESIGN section 4.1); the ADMM loop of the fused kernels runs a hundred times per solve and its selects are written out as
+    VOP3 (select_lanes / select64 in fccqp_fused_impl.h).  The loop is found by its one v_rsq_f64: nothing within the
+    ~125 instructions around it may be the VOP2 form, and there must be exactly the 60-odd DPP FMAs of the mat-vec in
+    front of it (the walking shape's kernels)."""
+    seen = 0
+    for _, _, dis in objects:
+        for name, body in dis.items():
+            if "fused_kernel" not in name or "ILi60ELi38ELi12ELi38" not in name or "Lb1" in name:
+                continue
+            rsq = [i for i, (mn, _) in enumerate(body) if mn.startswith("v_rsq_f64")]
+            assert rsq, f"{name}: no v_rsq_f64 (the cone projection)"
+            i0 = rsq[0]
+            window = body[max(0, i0 - 90):i0 + 60]
+            bad = [(mn, ops) for mn, ops in window if mn == "v_cndmask_b32_e32"]
+            assert not bad, f"{name}: {len(bad)} VOP2 selects in the ADMM loop, first: {bad[0]}"
+            assert sum(1 for mn, ops in window if mn.startswith("v_fmac_f64") and "row_newbcast" in ops) >= 60
+            seen += 1
+    assert seen >= 2

@@ -74,7 +74,7 @@ struct Shape {
   static_assert(nc % 3 == 0 && nc > 0 && s + nc <= n, "fcc_qp.cpp:32-33; shapes without contacts run on the generic kernel");
   static constexpr int kContacts = nc / 3;
   static_assert(4 * kContacts <= kPos, "one quad of lanes per contact");
-  using Reduced = Packed<n>;
+  using Reduced = ZeroFilledSquare<n>;              // factor of W: zero-filled square, select-free sweeps (fccqp_fused_impl.h)
   static constexpr int ownC(int J) { return J % W; }
   static constexpr int ownX(int cb) { return cb % W; }
   // column split c of the mat-vec owns the 16-column blocks [qlo(c), qlo(c + 1))
@@ -408,7 +408,21 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
   lds_f64 *const Vbuf = L + SH::kBig + SH::kWfac;
   lds_f64 *const Sblk = L + SH::kSblk, *const Sinv = L + SH::kSinv, *const Srcp = L + SH::kSrcp;
   lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
+  if constexpr (SW::kZeroFilled) {
+    // zeros on and above the diagonal of the square: every wave clears a slice of it (the rho G image it lies over is
+    // dead: barrier in front of this function), L then goes on top
+    static_assert(SW::kDinv % 2 == 0, "whole 16-byte stores");
+    lds_d2 *const z2 = reinterpret_cast<lds_d2 *>(M);
+    constexpr int kPairs = SW::kDinv / 2, kPerWave = (kPairs + SH::W - 1) / SH::W;
+#pragma unroll
+    for (int k = 0; k < (kPerWave + 63) / 64; ++k) {
+      const int idx = WV * kPerWave + 64 * k + lane;
+      if (64 * k + lane < kPerWave && idx < kPairs) z2[idx] = d2{0.0, 0.0};
+    }
+    wg_barrier();
+  }
   // diagonal tile of panel Pn, by its owner: column 16 Pn + col of L (tile_ldl leaves T = L d), 1/d in the diagonal slots
+  // (the slots behind the square in the zero-filled layout)
   auto factor_diag = [&](auto pn) {
     constexpr int Pn = decltype(pn)::value;
     constexpr int kValid = (n - 16 * Pn < 16) ? n - 16 * Pn : 16;
@@ -417,7 +431,7 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
     const bool bad = diag_tile<kValid, !kLast, true>(L, lane, C[Pn][Pn], T, rmine, 1.0 / min_pivot, Pn & 1);
     if (lane < 16 && col < kValid) {
       const int jcol = 16 * Pn + col, cb = SW::cbase(jcol);
-      M[cb + jcol] = rmine;
+      M[SW::kZeroFilled ? SW::kDinv + jcol : cb + jcol] = rmine;
 #pragma unroll
       for (int i = 1; i < kValid; ++i) {
         lds_f64 *dst = (i > col) ? M + cb + 16 * Pn + i : Sblk + col;      // (above the diagonal: a dummy slot)
@@ -521,7 +535,7 @@ __device__ __forceinline__ void solve_lds_slots(const lds_f64 *M, const int lane
 #pragma unroll
           for (int t = 0; t < SLOTS; ++t) {
             if (64 * t + 63 > k) {
-              const double a = (lane + 64 * t > k && lane + 64 * t < N) ? cur[u][t] : 0.0;
+              const double a = SW::kZeroFilled ? cur[u][t] : ((lane + 64 * t > k && lane + 64 * t < N) ? cur[u][t] : 0.0);
               x[t] = fma(-a, xk, x[t]);
             }
           }
@@ -534,7 +548,7 @@ __device__ __forceinline__ void solve_lds_slots(const lds_f64 *M, const int lane
     }
   }
 #pragma unroll
-  for (int t = 0; t < SLOTS; ++t) x[t] *= M[cbr[t] + rc[t]];          // 1/d (pseudo-inverse rule folded in)
+  for (int t = 0; t < SLOTS; ++t) x[t] *= M[SW::kZeroFilled ? SW::kDinv + rc[t] : cbr[t] + rc[t]];          // 1/d (pseudo-inverse rule folded in)
   // ---- backward with L^T: x_i -= L[k][i] x_k, i < k; L[k][i] = M[cbase(i) + k]: this lane's own columns --------
   {
     double cur[U][SLOTS], nxt[U][SLOTS];
@@ -556,7 +570,7 @@ __device__ __forceinline__ void solve_lds_slots(const lds_f64 *M, const int lane
 #pragma unroll
           for (int t = 0; t < SLOTS; ++t) {
             if (64 * t < k) {
-              const double a = (lane + 64 * t < k) ? cur[u][t] : 0.0;
+              const double a = SW::kZeroFilled ? cur[u][t] : ((lane + 64 * t < k) ? cur[u][t] : 0.0);
               x[t] = fma(-a, xk, x[t]);
             }
           }

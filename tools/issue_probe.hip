@@ -37,7 +37,6 @@
 #define MOVDPP32(acc, m) "v_mov_b32_dpp v" #acc ", v" #m " row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
 #define DSR(acc, m) "ds_read_b64 " R2(acc) ", v126\n\t"
 #define DSW(acc, m) "ds_write_b64 v126, " R2(m) "\n\t"
-#define SAND(acc, m) "s_and_b64 s[24:25], s[22:23], exec\n\t"
 #define WAITL(acc, m) "s_waitcnt lgkmcnt(0)\n\t"
 #define CMP(acc, m) "v_cmp_gt_f64_e64 s[24:25], " R2(acc) ", " R2(m) "\n\t"
 // 16 instances on four accumulators (100, 102, 104, 106), sixteen distinct second operands
@@ -133,7 +132,6 @@ KERNEL(k_movdpp32, X16(MOVDPP32))
 KERNEL(k_dsr, X16(DSR) "s_waitcnt lgkmcnt(0)\n\t")
 KERNEL(k_dsw, X16(DSW) "s_waitcnt lgkmcnt(0)\n\t")
 KERNEL(k_dsr1, DSR(100, 128) "s_waitcnt lgkmcnt(0)\n\t")
-KERNEL(k_sand, X16(SAND))
 KERNEL(k_waitl, X16(WAITL))
 typedef void (*kern_t)(long long *, int);
 void run(const char *name, kern_t k, long long *cyc, int per_trip) {
@@ -200,7 +198,6 @@ int main() {
   run("ds_read_b64 x16 + wait", k_dsr, cyc, 16);
   run("ds_write_b64 x16 + wait", k_dsw, cyc, 16);
   run("ds_read_b64 x1 + wait (round trip)", k_dsr1, cyc, 1);
-  run("s_and_b64 x16", k_sand, cyc, 16);
   run("s_waitcnt lgkmcnt(0) (nothing pending) x16", k_waitl, cyc, 16);
   return 0;
 }

@@ -139,6 +139,12 @@ __device__ __forceinline__ double quad_bcast(double v) {
   int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// component K of this lane's contact force: lane K of the quad, or -- one contact per 16-lane row -- of the row
+template <int K, bool ROW>
+__device__ __forceinline__ double contact_bcast(double v) {
+  if constexpr (ROW) return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, true);    // v_mov_b64_dpp row_newbcast:K
+  else return quad_bcast<K>(v);
+}
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_get<0xB1, 0xf>(v, 0.0);   // quad_perm [1,0,3,2]
   v += dpp_get<0x4E, 0xf>(v, 0.0);   // quad_perm [2,3,0,1]
@@ -316,18 +322,37 @@ struct Shape : Packed<N_VARS + N_EQ> {
   static constexpr int kVbuf = (kNp > kWave) ? kNp : kWave;
   static constexpr int kLdsDoubles = kMat + kVbuf;
   static_assert(kLdsDoubles * 8 <= 160 * 1024 / 4, "four one-wave workgroups per CU");
-  // Lane <-> variable map of the ADMM loop.  Contact c owns lanes 4c, 4c+1, 4c+2 (x, y, z): a lane
-  // gets the three components of its contact force with quad_perm DPP moves instead of an LDS round
-  // trip per iteration.  The other variables fill the fourth lane of those quads, then the lanes past
-  // the contacts, in increasing order.  -1: the lane has no variable.
+  // Lane <-> variable map of the ADMM loop.  A lane gets the three components of its contact's force with DPP
+  // moves instead of an LDS round trip per iteration: contact c owns lanes 16c, 16c+1, 16c+2 (x, y, z) of 16-lane row c
+  // when there are at most four contacts (kRowContacts below), else lanes 4c, 4c+1, 4c+2 of quad c.  The other
+  // variables fill the remaining lanes in increasing order.  -1: the lane has no variable.
   static constexpr int kContacts = nc / 3;
   static_assert(4 * kContacts <= kWave, "one quad of lanes per contact");
+  // Up to four contacts: contact c owns lanes 16c, 16c+1, 16c+2 -- one contact per 16-lane row -- and a lane gets a
+  // component of its contact's force with ONE v_mov_b64_dpp (row_newbcast, the fp64 DPP mode) instead of the two
+  // v_mov_b32 quad_perm moves a 64-bit value needs in the quad layout: three issue slots fewer per ADMM iteration.
+  static constexpr bool kRowContacts = kContacts <= 4;
+  __device__ static __forceinline__ bool lane_is_cone(const int lane) {
+    return kRowContacts ? ((lane >> 4) < kContacts && (lane & 15) < 3) : ((lane >> 2) < kContacts && (lane & 3) < 3);
+  }
+  __device__ static __forceinline__ int lane_contact(const int lane) { return kRowContacts ? (lane >> 4) : (lane >> 2); }
+  __device__ static __forceinline__ int lane_component(const int lane) { return kRowContacts ? (lane & 15) : (lane & 3); }
   __device__ static __forceinline__ int lane_variable(const int lane) {
-    const int q = lane >> 2, r = lane & 3;
-    const bool in_quad = q < kContacts;
-    const int k = in_quad ? q : lane - 3 * kContacts;      // index among the non-contact variables
-    const int other = (k < s) ? k : k + nc;
-    return (in_quad && r < 3) ? s + 3 * q + r : ((k < n - nc) ? other : -1);
+    if constexpr (kRowContacts) {
+      const int row = lane >> 4, pos = lane & 15;
+      const bool in_row = row < kContacts;
+      // contact lanes with a smaller index than this one
+      const int below = 3 * (in_row ? row : kContacts) + (in_row ? ((pos < 3) ? pos : 3) : 0);
+      const int k = lane - below;                            // index among the non-contact variables
+      const int other = (k < s) ? k : k + nc;
+      return (in_row && pos < 3) ? s + 3 * row + pos : ((k < n - nc) ? other : -1);
+    } else {
+      const int q = lane >> 2, r = lane & 3;
+      const bool in_quad = q < kContacts;
+      const int k = in_quad ? q : lane - 3 * kContacts;      // index among the non-contact variables
+      const int other = (k < s) ? k : k + nc;
+      return (in_quad && r < 3) ? s + 3 * q + r : ((k < n - nc) ? other : -1);
+    }
   }
 };
 
@@ -1202,9 +1227,9 @@ struct AdmmLane {
     var = SH::lane_variable(lane);
     isvar = var >= 0;
     vi = isvar ? var : 0;
-    is_cone = ((lane >> 2) < SH::kContacts) && ((lane & 3) < 3);
-    cidx = is_cone ? (lane >> 2) : 0;
-    ccomp = is_cone ? (lane & 3) : 0;
+    is_cone = SH::lane_is_cone(lane);
+    cidx = is_cone ? SH::lane_contact(lane) : 0;
+    ccomp = is_cone ? SH::lane_component(lane) : 0;
     mup = a.mu + (size_t)inst * (nc / 3);
     lbp = a.lb + (size_t)inst * n;
     ubp = a.ub + (size_t)inst * n;
@@ -1297,10 +1322,11 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
       // compiler puts a copy there.  An `s_nop 1` pinned here used to cost 16 cycles per iteration.)
       dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
       x = mv_total(acc);
-      // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in lanes 4c .. 4c+2 of
-      // this lane's quad: three quad_perm broadcasts (v_mov_b32 DPP pairs), no LDS round trip
+      // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in the first three lanes of this
+      // lane's 16-lane row (or quad, Shape::kRowContacts): three DPP broadcasts, no LDS round trip
       const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused
-      const double cfx = quad_bcast<0>(xm), cfy = quad_bcast<1>(xm), cfz = quad_bcast<2>(xm);
+      constexpr bool kRow = SH::kRowContacts;
+      const double cfx = contact_bcast<0, kRow>(xm), cfy = contact_bcast<1, kRow>(xm), cfz = contact_bcast<2, kRow>(xm);
       // Every lane runs both updates, unmasked (a select per state variable per iteration otherwise).  A
       // lane without a variable has x = mu_x = 0 and infinite bounds: it stays at zero.  Outside the
       // contacts lcbar / lr / mulc are garbage that nothing reads: w, the exit test, the reported norms
@@ -1353,7 +1379,7 @@ __device__ __forceinline__ void epilogue_writeback(const KernelArgs &a, const Ad
   const double *lbp = L.lbp, *ubp = L.ubp, *mup = L.mup;
   double *xs = L.xs;
   lds_fence();
-  const double ffy = quad_bcast<1>(x), ffz = quad_bcast<2>(x);   // this quad's contact force
+  const double ffy = contact_bcast<1, SH::kRowContacts>(x), ffz = contact_bcast<2, SH::kRowContacts>(x);   // this lane's contact force
   double bv = 0.0, cv = 0.0;
   if (isvar) {
     const double tt = min2(x, fresh(ubp)[vi]);

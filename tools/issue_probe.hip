@@ -133,6 +133,14 @@ KERNEL(k_dsr, X16(DSR) "s_waitcnt lgkmcnt(0)\n\t")
 KERNEL(k_dsw, X16(DSW) "s_waitcnt lgkmcnt(0)\n\t")
 KERNEL(k_dsr1, DSR(100, 128) "s_waitcnt lgkmcnt(0)\n\t")
 KERNEL(k_waitl, X16(WAITL))
+#define X64(OP) X16(OP) X16(OP) X16(OP) X16(OP)
+KERNEL(k_dpp64, X64(DPP))
+KERNEL(k_dpp128, X64(DPP) X64(DPP))
+KERNEL(k_cnds64, X64(CNDS))
+KERNEL(k_smov64, X64(SMOV))
+KERNEL(k_nop64, X64(NOP0))
+KERNEL(k_cndv64, X64(CNDV))
+KERNEL(k_rcp64, X64(RCP))
 typedef void (*kern_t)(long long *, int);
 void run(const char *name, kern_t k, long long *cyc, int per_trip) {
   const int blocks = 1024, iters = 2000;
@@ -199,5 +207,13 @@ int main() {
   run("ds_write_b64 x16 + wait", k_dsw, cyc, 16);
   run("ds_read_b64 x1 + wait (round trip)", k_dsr1, cyc, 1);
   run("s_waitcnt lgkmcnt(0) (nothing pending) x16", k_waitl, cyc, 16);
+  // the same instructions in longer loop bodies: (ticks per trip) = (instructions) x (cost) + (loop overhead)
+  run("v_fmac_f64_dpp x64", k_dpp64, cyc, 64);
+  run("v_fmac_f64_dpp x128", k_dpp128, cyc, 128);
+  run("v_cndmask_b32_e64 x64", k_cnds64, cyc, 64);
+  run("s_mov_b32 x64", k_smov64, cyc, 64);
+  run("s_nop 0 x64", k_nop64, cyc, 64);
+  run("v_cndmask_b32_e32 (vcc) x64", k_cndv64, cyc, 64);
+  run("v_rcp_f64 x64", k_rcp64, cyc, 64);
   return 0;
 }

@@ -76,6 +76,16 @@ struct fccqp_solver {
   // batch: a batch whose instances all need the COD pass ran on 64 of the 1024 wave slots.  Now one
   // per instance up to a full grid, bounded by 256 MiB of COD workspace (2 N^2 doubles per block).
   int fb_blocks = 1;
+  // The list is empty for all but degenerate inputs, and a full grid of the generic kernel that finds it empty still
+  // costs 6.4 us of every solve (1024 workgroups with ~60 KB of LDS each to dispatch), 64 workgroups 2.7 us.  Block 0 of
+  // every fallback launch leaves the length of its list in page-locked host memory (fb_seen, device alias fb_seen_dev);
+  // the next launches use the full grid while a recent one was non-empty (or nothing is known yet) and
+  // kFbSmallGrid workgroups otherwise.  A performance heuristic only: the persistent workgroups walk the whole list
+  // whatever their number.
+  static constexpr int kFbSmallGrid = 64, kFbFullFor = 8;
+  volatile int *fb_seen = nullptr;
+  int *fb_seen_dev = nullptr;
+  int fb_full_left = kFbFullFor;
   long long work_stride = 0;
   // two-launch form of the fused kernel (FCCQP_KERNEL_FUSED_SPLIT): rows of rho G + x_c, allocated on first use
   double *dsplit = nullptr;
@@ -287,9 +297,14 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   if (fb) {
     // fallback launch over the (normally empty) device list: COD x0, then ADMM from it.  It also
     // zeroes the other counter, which the next solve's main kernel will append to.
-    const int blocks = s->fb_blocks;
+    int blocks = s->fb_blocks;
+    if (s->fb_seen) {
+      if (*s->fb_seen != 0) s->fb_full_left = fccqp_solver::kFbFullFor;
+      else if (s->fb_full_left > 0) --s->fb_full_left;
+      if (s->fb_full_left == 0 && blocks > fccqp_solver::kFbSmallGrid) blocks = fccqp_solver::kFbSmallGrid;
+    }
     fccqp::KernelArgs b = a;
-    b.fb_list = nullptr; b.fb_count = nullptr;
+    b.fb_list = nullptr; b.fb_count = s->fb_seen_dev;        // (list mode: where block 0 reports the list's length)
 #ifdef FCCQP_TICKET_DISPATCH
     b.ticket = nullptr;
 #endif
@@ -457,6 +472,16 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
       s->fb_blocks = (int)(blocks < 1 ? 1 : blocks);
     }
     HIP_TRY(s, dmalloc(&s->dcod_ws, (size_t)s->fb_blocks * (size_t)s->cod_stride));
+    {
+      void *h = nullptr, *d = nullptr;
+      if (hipHostMalloc(&h, sizeof(int), hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+        s->fb_seen = static_cast<volatile int *>(h);
+        s->fb_seen_dev = static_cast<int *>(d);
+        *s->fb_seen = 1;                                     // nothing known yet: full grid
+      } else if (h) {
+        (void)hipHostFree(h);
+      }
+    }
     return FCCQP_OK;
   }();
   if (rc != FCCQP_OK) {
@@ -476,6 +501,7 @@ int fccqp_destroy(fccqp_solver *s) {
                   s->dwork, s->dphase, s->dfb_list, s->dfb_count, s->dcod_ws, s->dticket, s->dsplit};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (s->fb_seen) (void)hipHostFree(const_cast<int *>(s->fb_seen));
   if (s->hin_block) (void)hipHostFree(s->hin_block);
   if (s->hres_block) (void)hipHostFree(s->hres_block);
   if (s->ev0) (void)hipEventDestroy(s->ev0);

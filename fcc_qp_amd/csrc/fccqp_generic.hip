@@ -1862,7 +1862,13 @@ __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void gene
   };
   if (a.inst_list) {  // list mode (fallback launch): persistent blocks walk the fallback list
     const int total = *a.inst_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.next_count = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      *a.next_count = 0;
+      // (list mode does not append: fb_list is null.  fb_count then points at a word of page-locked host memory in
+      // which the host finds, some time later, how long this launch's list was -- fccqp_capi.cpp sizes the NEXT
+      // fallback launch by it)
+      if (a.fb_count) *a.fb_count = total;
+    }
     for (int li = blockIdx.x; li < total; li += gridDim.x) run(a.inst_list[li], true);
   } else {
     // block -> instance map (fccqp_device.h)

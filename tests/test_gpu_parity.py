@@ -262,6 +262,32 @@ def test_rank_deficient_presolve_uses_device_cod(oracle, kernel):
         assert d2[i].flags & CAPI.FLAG_PRESOLVE_NUMERICAL and not (d2[i].flags & CAPI.FLAG_PRESOLVE_COD)
 
 
+def test_fallback_grid_adapts_without_changing_results():
+    """The fallback-list launch uses 64 persistent workgroups instead of a full grid once the lists of recent solves
+    were empty (fccqp_capi.cpp, kFbSmallGrid).  The workgroups walk the whole list whatever their number: a batch
+    with more singular instances than that, solved on a handle that has seen only clean batches, must come out
+    bit-identical to the same batch on a fresh handle (full grid)."""
+    nb = 160
+    clean = P.workload("W-mix", nb, P.WALKING, distinct=16)
+    qps = [clean.instance(i) for i in range(nb)]
+    dead = [i for i in range(nb) if i % 8 != 3]                       # 140 of 160 need the COD pass
+    for i in dead:
+        qps[i] = _dead_variable(qps[i], 20 + (i % 10))
+    bad = P.stack(qps)
+    fresh = CAPI.Solver(*P.WALKING.ctor_args, batch=nb)
+    z0, it0, d0, _ = gpu_solve(P.WALKING, P.HARNESS_OPTIONS, bad, CAPI.KERNEL_AUTO, solver=fresh)
+    used = CAPI.Solver(*P.WALKING.ctor_args, batch=nb)
+    for _ in range(12):                                                # long enough for the small grid to take over
+        gpu_solve(P.WALKING, P.HARNESS_OPTIONS, clean, CAPI.KERNEL_AUTO, solver=used)
+    z1, it1, d1, _ = gpu_solve(P.WALKING, P.HARNESS_OPTIONS, bad, CAPI.KERNEL_AUTO, solver=used)
+    assert np.array_equal(z1.view(np.uint64), z0.view(np.uint64)) and np.array_equal(it1, it0)
+    for i in range(nb):
+        assert bool(d1[i].flags & CAPI.FLAG_PRESOLVE_COD) == (i in set(dead))
+    # and once more, now on the full grid again
+    z2, it2, _, _ = gpu_solve(P.WALKING, P.HARNESS_OPTIONS, bad, CAPI.KERNEL_AUTO, solver=used)
+    assert np.array_equal(z2.view(np.uint64), z0.view(np.uint64)) and np.array_equal(it2, it0)
+
+
 def test_cod_fallback_equality_only_is_the_pseudo_inverse(oracle):
     """nc == 0, infinite bounds, semi-definite cost: x = (pinv(K) [-b; b_eq]).head(n), n_iter = 0."""
     n, m = 6, 2

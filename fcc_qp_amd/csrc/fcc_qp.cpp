@@ -161,6 +161,9 @@ void FCCQPBatch::set_warm_start(bool warm_start) {
   check(fccqp_set_warm_start(h_, warm_start ? 1 : 0), h_, "FCCQPBatch::set_warm_start");
 }
 void FCCQPBatch::set_kernel(int kernel) { check(fccqp_set_kernel(h_, kernel), h_, "FCCQPBatch::set_kernel"); }
+void FCCQPBatch::set_kernel_timing(bool enabled) {
+  check(fccqp_set_kernel_timing(h_, enabled ? 1 : 0), h_, "FCCQPBatch::set_kernel_timing");
+}
 int FCCQPBatch::kernel_in_use() const {
   int k = 0;
   check(fccqp_get_kernel(h_, &k), h_, "FCCQPBatch::kernel_in_use");
@@ -243,6 +246,9 @@ void FCCQPSharded::set_warm_start(bool warm_start) {
 }
 void FCCQPSharded::set_kernel(int kernel) {
   for (auto *h : h_) check(fccqp_set_kernel(h, kernel), h, "FCCQPSharded::set_kernel");
+}
+void FCCQPSharded::set_kernel_timing(bool enabled) {
+  for (auto *h : h_) check(fccqp_set_kernel_timing(h, enabled ? 1 : 0), h, "FCCQPSharded::set_kernel_timing");
 }
 
 void FCCQPSharded::Solve(const double *Q, const double *b, const double *A_eq, const double *b_eq,

@@ -139,6 +139,7 @@ class FCCQPBatch {
   void set_options(FCCQPOptions opt);
   void set_warm_start(bool warm_start);
   void set_kernel(int kernel);  // FCCQP_KERNEL_*
+  void set_kernel_timing(bool enabled);  // fccqp_set_kernel_timing: the start event of every solve (on by default)
   int kernel_in_use() const;
   FCCQPOptions get_options() const { return options_; }
 
@@ -192,6 +193,7 @@ class FCCQPSharded {
   void set_options(FCCQPOptions opt);
   void set_warm_start(bool warm_start);
   void set_kernel(int kernel);
+  void set_kernel_timing(bool enabled);
   FCCQPOptions get_options() const { return options_; }
 
   // host pointers to the whole batch; n_friction = friction coefficients per instance (>= nc/3)

@@ -68,6 +68,8 @@ struct fccqp_solver {
   long long *dticks = nullptr;
   long long *dphase = nullptr;  // [8][batch], allocated on demand
   bool fallback = true;          // device COD fallback for a rank-deficient presolve
+  bool kernel_timing = true;     // record the start event of every solve (fccqp_set_kernel_timing)
+  bool timed = false;            // ... and whether the last solve did
   int *dfb_list = nullptr, *dfb_count = nullptr;  // dfb_count[2]: used alternately, see enqueue()
   unsigned solve_seq = 0;
   double *dcod_ws = nullptr;
@@ -262,7 +264,8 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   }
   // (ordering against the previous solve: order_after_previous, called by the entry points)
   // (defer_fallback is the synchronous small-batch path: its caller waits on the host and records no events)
-  if (!defer_fallback) HIP_TRY(s, hipEventRecord(s->ev0, stream));
+  s->timed = s->kernel_timing && !defer_fallback;
+  if (s->timed) HIP_TRY(s, hipEventRecord(s->ev0, stream));
   hipError_t e;
   if (kernel == FCCQP_KERNEL_COOP) {
     s->kernel_used = FCCQP_KERNEL_COOP;
@@ -537,6 +540,11 @@ int fccqp_set_kernel(fccqp_solver *s, int kernel) {
 int fccqp_set_presolve_fallback(fccqp_solver *s, int enabled) {
   if (!s) return FCCQP_ERR_INVALID_ARG;
   s->fallback = enabled != 0;
+  return FCCQP_OK;
+}
+int fccqp_set_kernel_timing(fccqp_solver *s, int enabled) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  s->kernel_timing = enabled != 0;
   return FCCQP_OK;
 }
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {
@@ -859,7 +867,7 @@ int fccqp_get_solution(fccqp_solver *s, double *z, fccqp_details *details) {
     double wall = s->last_solve_wall;
     if (wall == 0.0) {  // device-pointer solve: report the kernel time instead
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) wall = 1e-3 * (double)ms;
+      if (s->timed && hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) wall = 1e-3 * (double)ms;
     }
     for (size_t i = 0; i < B; ++i) {
       fccqp_details &d = details[i];
@@ -924,6 +932,7 @@ int fccqp_last_kernel_ms(fccqp_solver *s, float *ms) {
     *ms = s->host_device_ms;
     return FCCQP_OK;
   }
+  if (!s->timed) return fail(s, FCCQP_ERR_UNSUPPORTED, "kernel timing is switched off (fccqp_set_kernel_timing)");
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
   return FCCQP_OK;

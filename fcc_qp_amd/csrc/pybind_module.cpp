@@ -219,6 +219,7 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def("set_warm_start", &FCCQPBatch::set_warm_start)
       .def("set_options", &FCCQPBatch::set_options)
       .def("set_kernel", &FCCQPBatch::set_kernel)
+      .def("set_kernel_timing", &FCCQPBatch::set_kernel_timing, py::arg("enabled"))
       .def("kernel_in_use", &FCCQPBatch::kernel_in_use)
       .def_property_readonly("batch", &FCCQPBatch::batch)
       .def_property_readonly("num_vars", &FCCQPBatch::num_vars)
@@ -295,6 +296,7 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def("set_options", &fcc_qp::FCCQPSharded::set_options)
       .def("set_warm_start", &fcc_qp::FCCQPSharded::set_warm_start)
       .def("set_kernel", &fcc_qp::FCCQPSharded::set_kernel)
+      .def("set_kernel_timing", &fcc_qp::FCCQPSharded::set_kernel_timing, py::arg("enabled"))
       .def_property_readonly("batch", &fcc_qp::FCCQPSharded::batch)
       .def_property_readonly("shards", &fcc_qp::FCCQPSharded::shards)
       .def("shard_begin", &fcc_qp::FCCQPSharded::shard_begin)

@@ -136,6 +136,13 @@ int fccqp_set_kernel(fccqp_solver *s, int kernel);   /* FCCQP_KERNEL_* */
  * branch, reference src/fcc_qp.cpp:164-166,176).  On by default; costs two near-empty kernel
  * launches per solve when no instance needs it. */
 int fccqp_set_presolve_fallback(fccqp_solver *s, int enabled);
+/* The start-of-kernel event of a solve (what fccqp_last_kernel_ms and, for device-pointer solves,
+ * fccqp_details.solve_time are measured from).  On by default.  A hipEventRecord in front of the kernel makes the
+ * kernel wait for the stream to drain -- ~5 us per solve, 1.5 % of a 4096-instance walking-shape batch -- so a
+ * caller that times its solves itself can switch it off: fccqp_last_kernel_ms then returns FCCQP_ERR_UNSUPPORTED
+ * and solve_time of a device-pointer solve is 0.  (No counterpart in the reference, whose solve_time is a host
+ * chrono pair, src/fcc_qp.cpp:115,188.) */
+int fccqp_set_kernel_timing(fccqp_solver *s, int enabled);
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use);
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
                     int *lambda_c_start, int *batch, int *device);

@@ -59,6 +59,7 @@ def lib():
         L.fccqp_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_set_kernel.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_set_presolve_fallback.argtypes = [C.c_void_p, C.c_int]
+        L.fccqp_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_get_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.fccqp_solve.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.fccqp_solve_device.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]
@@ -119,6 +120,9 @@ class Solver:
 
     def set_presolve_fallback(self, on):
         self._ck(self.L.fccqp_set_presolve_fallback(self.h, int(bool(on))), "set_presolve_fallback")
+
+    def set_kernel_timing(self, on):
+        self._ck(self.L.fccqp_set_kernel_timing(self.h, int(bool(on))), "set_kernel_timing")
 
     def kernel(self):
         k = C.c_int()

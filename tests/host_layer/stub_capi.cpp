@@ -49,6 +49,7 @@ int fccqp_get_options(const fccqp_solver *s, fccqp_options *o) { *o = s->opt; re
 int fccqp_set_warm_start(fccqp_solver *s, int w) { s->warm = w; return FCCQP_OK; }
 int fccqp_set_kernel(fccqp_solver *s, int k) { s->kernel = k; return FCCQP_OK; }
 int fccqp_set_presolve_fallback(fccqp_solver *, int) { return FCCQP_OK; }
+int fccqp_set_kernel_timing(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_get_kernel(const fccqp_solver *s, int *k) { *k = s->kernel; return FCCQP_OK; }
 int fccqp_get_shape(const fccqp_solver *s, int *n, int *m, int *nc, int *st, int *b, int *d) {
   if (n) *n = s->n; if (m) *m = s->m; if (nc) *nc = s->nc; if (st) *st = s->s; if (b) *b = s->batch; if (d) *d = s->device;

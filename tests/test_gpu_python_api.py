@@ -367,3 +367,31 @@ def test_async_host_solve_from_pinned_memory(oracle):
                                C._p(arrs[5]), C._p(arrs[6])) == C.ERR_FRICTION
     for a in pinned:
         assert L.fccqp_host_unregister(a.ctypes.data) == C.OK
+
+
+@pytest.mark.gpu
+def test_kernel_timing_switch():
+    """fccqp_set_kernel_timing(0): no start event in front of the kernel; results unchanged, LastKernelMilliseconds
+    refuses, solve_time of a device-pointer solve is 0; switching it back on restores both."""
+    import torch
+    import fcc_qp_amd as F
+    nb = 64
+    B = P.workload("W-mix", nb, P.WALKING)
+    tens = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in B.arrays()]
+    s = F.FCCQPBatch(*P.WALKING.ctor_args, nb, 0)
+    o = F.FCCQPOptions(); h = P.HARNESS_OPTIONS
+    o.max_iter, o.rho, o.eps_fcone, o.eps_bound = h["max_iter"], h["rho"], h["eps_fcone"], h["eps_bound"]
+    s.set_options(o)
+    F.solve_tensors(s, *tens); torch.cuda.synchronize()
+    z_on = np.array(s.GetSolution().z, copy=True)
+    assert s.LastKernelMilliseconds() > 0.0
+    s.set_kernel_timing(False)
+    F.solve_tensors(s, *tens); torch.cuda.synchronize()
+    sol = s.GetSolution()
+    assert np.array_equal(np.asarray(sol.z), z_on)
+    assert sol[0].details.solve_time == 0.0
+    with pytest.raises(Exception):
+        s.LastKernelMilliseconds()
+    s.set_kernel_timing(True)
+    F.solve_tensors(s, *tens); torch.cuda.synchronize()
+    assert s.LastKernelMilliseconds() > 0.0 and s.GetSolution()[0].details.solve_time > 0.0

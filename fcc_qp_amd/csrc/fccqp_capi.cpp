@@ -79,7 +79,7 @@ struct fccqp_solver {
   // per instance up to a full grid, bounded by 256 MiB of COD workspace (2 N^2 doubles per block).
   int fb_blocks = 1;
   // The list is empty for all but degenerate inputs, and a full grid of the generic kernel that finds it empty still
-  // costs 6.4 us of every solve (1024 workgroups with ~60 KB of LDS each to dispatch), 64 workgroups 2.7 us.  Block 0 of
+  // costs 6.4 us of every solve (1024 workgroups with ~60 KB of LDS each to dispatch), 64 workgroups 3.7 us less.  Block 0 of
   // every fallback launch leaves the length of its list in page-locked host memory (fb_seen, device alias fb_seen_dev);
   // the next launches use the full grid while a recent one was non-empty (or nothing is known yet) and
   // kFbSmallGrid workgroups otherwise.  A performance heuristic only: the persistent workgroups walk the whole list

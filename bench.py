@@ -187,16 +187,31 @@ def cpu_baseline(shape, options, batch_obj, log):
 
 
 def _timed_steps(torch, step, steps, warmup):
-    """W untimed + K timed steps of `step` on torch's current stream; (wall seconds, kernel ms per step)."""
+    """W untimed + K timed steps of `step` on torch's current stream, back to back, ONE HIP event pair around the
+    K steps (an event between two steps makes the second wait for the stream to drain: ~5 us of stream time each,
+    DESIGN.md section 4.3); returns (wall seconds, ms per launch = event span / K as a one-element list)."""
     for _ in range(warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, [e0.elapsed_time(e1) / steps]
+
+
+def _isolated_launch_ms(torch, step, steps):
+    """K more steps, each between its own HIP event pair (the stream drains in front of every step): the duration of
+    ONE launch with nothing in front of it -- what a rocprofv3 kernel trace of such a run reports per dispatch."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
     for e0, e1 in ev:
         e0.record(); step(); e1.record()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, [e0.elapsed_time(e1) for e0, e1 in ev]
+    return [e0.elapsed_time(e1) for e0, e1 in ev]
 
 
 def _parity(O, shape, options, batch, z, n_iter, k):
@@ -275,11 +290,49 @@ def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup
     run("large_shape", P.LARGE, "W-sat", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
     run("large_shape_generic", P.LARGE, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_GENERIC, distinct=32, parity_k=16, steps=4, warmup=1)
     run("large_shape_w_mix", P.LARGE, "W-mix", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
+    out["two_streams"] = two_streams(F, P, torch, dev, dev_index, log)
     out["batch_sweep"] = batch_sweep(F, P, torch, dev, dev_index, log)
     out["single_instance"] = single_instance(F, P, log)
     out["end_to_end"] = end_to_end(P, O, dev_index, log)
     out["end_to_end_f32"] = end_to_end(P, O, dev_index, log, f32=True)
     return out
+
+
+def two_streams(F, P, torch, dev, dev_index, log, steps=20, warmup=4):
+    """The headline workload as a continuous feed: two solver handles on two HIP streams, steps alternating between
+    them, so that the tail of one launch (the last of its four wave-rounds draining) overlaps the head of the next.
+    Each handle owns its outputs and state, so the two launches share nothing.  NOT the headline: `value` times the
+    steps of ONE handle in stream order."""
+    import numpy as np
+    nb = BATCH_PER_GPU
+    batch = P.workload("W-sat", nb, P.WALKING, distinct=256)
+    sets = [[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in batch.arrays()] for _ in range(2)]
+    solvers, streams = [], [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for _ in range(2):
+        sv = F.FCCQPBatch(*P.WALKING.ctor_args, nb, dev_index)
+        sv.set_kernel_timing(False)
+        o = F.FCCQPOptions()
+        o.max_iter, o.rho, o.eps_fcone, o.eps_bound = (P.HARNESS_OPTIONS[k] for k in ("max_iter", "rho", "eps_fcone", "eps_bound"))
+        sv.set_options(o)
+        solvers.append(sv)
+
+    def run(k):
+        for i in range(k):
+            F.solve_tensors(solvers[i & 1], *sets[i & 1], stream=streams[i & 1])
+
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    z0, z1 = (np.asarray(sv.GetSolution().z) for sv in solvers)
+    rec = {"value": nb * steps / wall, "unit": "solves/s", "ms_per_step": 1e3 * wall / steps, "handles": 2, "streams": 2,
+           "results_bit_identical_across_handles": bool(np.array_equal(z0, z1)),
+           "workload": "W-sat FCCQP(60, 38, 12, 38) cold max_iter=100, 256 distinct instances tiled to 4096, steps "
+                       "alternating between two handles on two streams"}
+    log(f"[bench] two_streams: {rec['value'] / 1e6:.3f} M solves/s, {rec['ms_per_step']:.3f} ms per step")
+    return rec
 
 
 def batch_sweep(F, P, torch, dev, dev_index, log):
@@ -512,20 +565,25 @@ def main():
         solver.set_warm_start(True)     # state (x, mu) stays resident; the presolve is skipped (fcc_qp.cpp:159)
     for _ in range(args.warmup):
         step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # ONE HIP event pair around the K timed steps (on the launch stream): the steps run back to back, as the
+    # contract's timed region says; an event between two steps would make the second wait for the stream to drain.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     S.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for e0, e1 in ev:
-        e0.record()
+    ev0.record()
+    for _ in range(args.steps):
         step()
-        e1.record()
+    ev1.record()
     torch.cuda.synchronize()
     S.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
-    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in ev]        # HIP events on the launch stream
+    region_ms = ev0.elapsed_time(ev1)                          # HIP events over the timed region
+    kernel_ms = [region_ms / args.steps]                       # average launch duration inside it
+    # beside it (outside the timed region): every launch between its own event pair, the stream drained in front
+    isolated_ms = _isolated_launch_ms(torch, step, min(args.steps, 20))
 
     red_dev = dev if (world > 1 and dist.get_backend() == "nccl") else None
     elapsed = S.max_over_ranks(elapsed, red_dev)      # the slowest rank defines the step time
@@ -570,7 +628,11 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel_ms_mean": mean_ms, "kernel_ms_min": float(np.min(kernel_ms)),
+                         "kernel_ms_mean": mean_ms, "kernel_ms_isolated_mean": float(np.mean(isolated_ms)),
+                         "kernel_ms_isolated_min": float(np.min(isolated_ms)),
+                         "timing": "kernel_ms_mean = HIP-event span of the K back-to-back timed steps / K (includes the "
+                                   "near-empty fallback-list launch of every step); kernel_ms_isolated_*: K more steps, "
+                                   "each between its own event pair with the stream drained in front",
                          "algorithmic_bytes_per_launch": alg_bytes},
             # diagnostic beside the contractual HBM roofline: algorithmic flops
             # F = f N^3/3 + (p + K) 2 N^2 per solve against the 78.6 TFLOP/s vector-fp64 peak

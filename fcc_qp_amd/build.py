@@ -51,7 +51,8 @@ def hipcc() -> str:
 
 def build_lib(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip",
-                                            "fccqp_fused_f32.hip", "fccqp_fused_split.hip", "fccqp_coop.hip")]
+                                            "fccqp_fused_f32.hip", "fccqp_fused_split.hip", "fccqp_coop.hip",
+                                            "fccqp_check.hip")]
     deps = srcs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
                           os.path.join(CSRC, "fccqp_coop_impl.h"), os.path.join(CSRC, "coop_shapes.def"),
                           os.path.join(CSRC, "fused_shapes.def"),
@@ -80,7 +81,7 @@ def build_lib(force: bool = False) -> str:
                       "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-c", src, "-o", obj])
 
         # the translation units are independent
-        with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as pool:
+        with ThreadPoolExecutor(max_workers=min(7, len(srcs))) as pool:
             list(pool.map(compile_one, zip(srcs, objs)))
         _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
     return LIB

@@ -205,6 +205,15 @@ FCCQPBatchSolution FCCQPBatch::GetSolution() const {
   for (const auto &x : d) out.details.push_back(from_c(x));
   return out;
 }
+void FCCQPBatch::set_self_check(bool enabled) {
+  check(fccqp_set_self_check(h_, enabled ? 1 : 0), h_, "FCCQPBatch::set_self_check");
+}
+std::pair<float, int> FCCQPBatch::LastTiming() const {
+  float ms = 0.f;
+  int by = FCCQP_TIMING_NONE;
+  check(fccqp_last_timing(h_, &ms, &by), h_, "FCCQPBatch::LastTiming");
+  return {ms, by};
+}
 float FCCQPBatch::LastKernelMilliseconds() const {
   float ms = 0.f;
   check(fccqp_last_kernel_ms(h_, &ms), h_, "FCCQPBatch::LastKernelMilliseconds");

@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 
@@ -140,6 +141,7 @@ class FCCQPBatch {
   void set_warm_start(bool warm_start);
   void set_kernel(int kernel);  // FCCQP_KERNEL_*
   void set_kernel_timing(bool enabled);  // fccqp_set_kernel_timing: the start event of every solve (on by default)
+  void set_self_check(bool enabled);     // fccqp_set_self_check: A_eq z = b_eq re-checked behind every solve (FLAG_EQ_RESIDUAL)
   int kernel_in_use() const;
   FCCQPOptions get_options() const { return options_; }
 
@@ -158,6 +160,8 @@ class FCCQPBatch {
   void Synchronize();
   FCCQPBatchSolution GetSolution() const;
   float LastKernelMilliseconds() const;
+  // the same with how it was measured (FCCQP_TIMING_*: device events, host clock of the low-latency path, or none)
+  std::pair<float, int> LastTiming() const;
   long long AlgorithmicBytes() const;
 
   int batch() const { return batch_; }

@@ -69,6 +69,8 @@ struct fccqp_solver {
   long long *dphase = nullptr;  // [8][batch], allocated on demand
   bool fallback = true;          // device COD fallback for a rank-deficient presolve
   bool kernel_timing = true;     // record the start event of every solve (fccqp_set_kernel_timing)
+  bool self_check = false;       // equality-residual check behind every solve (fccqp_set_self_check; on for N > 256)
+  fccqp::KernelArgs check_args{}; // ... its arguments for a deferred fallback pass (run_deferred_fallback)
   bool timed = false;            // ... and whether the last solve did
   int *dfb_list = nullptr, *dfb_count = nullptr;  // dfb_count[2]: used alternately, see enqueue()
   unsigned solve_seq = 0;
@@ -151,6 +153,8 @@ size_t n_mu(const fccqp_solver *s) { return (size_t)(s->nc / 3); }
 
 // host-pointer solves of at most this many bytes go through the page-locked mirror blocks
 constexpr size_t kPinnedMirrorBytes = 1u << 20;
+// relative tolerance of the equality-residual self-check (fccqp_check.hip)
+constexpr double kSelfCheckTol = 1e-6;
 size_t align256(size_t v) { return (v + 255u) & ~size_t(255); }
 
 int ensure_staging(fccqp_solver *s) {
@@ -328,6 +332,13 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
     }
     if (!defer_fallback) s->solve_seq++;
   }
+  if (s->self_check) {
+    // behind the main kernel and (when it is not deferred) the fallback pass, in front of the end event and of any
+    // copy of the results; a deferred fallback pass is followed by a second check (run_deferred_fallback)
+    s->check_args = a;
+    e = fccqp::launch_eq_residual_check(a, stream, qa_f32, kSelfCheckTol);
+    if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "self-check launch", e);
+  }
   if (!defer_fallback) HIP_TRY(s, hipEventRecord(s->ev1, stream));
   s->last_stream = stream;
   s->last_was_warm = s->warm_start;
@@ -357,7 +368,25 @@ int run_deferred_fallback(fccqp_solver *s, hipStream_t stream) {
     return fail(s, FCCQP_ERR_HIP, "fallback kernel launch", e);
   }
   s->solve_seq++;
+  if (s->self_check) {
+    e = fccqp::launch_eq_residual_check(s->check_args, stream, s->pending_fb_f32, kSelfCheckTol);
+    if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "self-check launch", e);
+  }
   return FCCQP_OK;
+}
+
+// A failure after enqueue(.., defer_fallback = true): no end event was recorded and the main kernel may have appended
+// to the fallback list that nobody is going to consume.  Leave the handle as after a finished solve with empty
+// lists: both counters cleared, nothing pending, nothing to wait for.
+int abandon_deferred(fccqp_solver *s, hipStream_t stream, const char *what, hipError_t e) {
+  (void)hipMemsetAsync(s->dfb_count, 0, 2 * sizeof(int), stream);
+  s->fb_deferred = false;
+  (void)hipStreamSynchronize(stream);
+  (void)hipGetLastError();
+  s->hres_fresh = false;
+  s->quiesced = true;
+  s->host_device_ms = 0.f;
+  return fail(s, FCCQP_ERR_HIP, what, e);
 }
 
 }  // namespace
@@ -409,6 +438,7 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
   if (!s) return FCCQP_ERR_ALLOC;
   s->n = num_vars; s->m = num_equality_constraints; s->nc = nc; s->s = lambda_c_start;
   s->batch = batch; s->device = device;
+  s->self_check = num_vars + num_equality_constraints > fccqp::kSelfCheckAboveN;
   DeviceGuard g(device);
   if (!g.ok) { delete s; return FCCQP_ERR_NO_DEVICE; }
 
@@ -547,6 +577,11 @@ int fccqp_set_kernel_timing(fccqp_solver *s, int enabled) {
   s->kernel_timing = enabled != 0;
   return FCCQP_OK;
 }
+int fccqp_set_self_check(fccqp_solver *s, int enabled) {
+  if (!s) return FCCQP_ERR_INVALID_ARG;
+  s->self_check = enabled != 0;
+  return FCCQP_OK;
+}
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {
   if (!s || !kernel_in_use) return FCCQP_ERR_INVALID_ARG;
   if (s->solved) {   // what the last solve ran (unaligned Q / A_eq fall back to the generic kernel)
@@ -654,15 +689,24 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
     const bool defer = wait && s->hres_block != nullptr;      // flags come back with the results: look before launching the list pass
     const auto t_launch = std::chrono::high_resolution_clock::now();
     rc = enqueue(s, at(0), at(1), at(2), at(3), at(4), at(5), at(6), st, /*qa_f32=*/false, defer);
-    if (rc != FCCQP_OK) return rc;
+    if (rc != FCCQP_OK) {
+      if (defer) {           // (the main kernel may already run: same clean-up as for a failure behind it)
+        const std::string msg = s->err;
+        (void)abandon_deferred(s, st, "enqueue", hipSuccess);
+        s->err = msg;
+      }
+      return rc;
+    }
     if (!wait) {
       s->last_solve_wall = 0.0;
       return FCCQP_OK;
     }
     if (defer) {
-      // results behind the kernel, one synchronisation for both; GetSolution then copies nothing
-      HIP_TRY(s, hipMemcpyAsync(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost, st));
-      HIP_TRY(s, spin_synchronize(st));
+      // results behind the kernel, one synchronisation for both; GetSolution then copies nothing.  (A failure from
+      // here on leaves no end event and perhaps a fallback list without a consumer: abandon_deferred.)
+      hipError_t he = hipMemcpyAsync(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost, st);
+      if (he == hipSuccess) he = spin_synchronize(st);
+      if (he != hipSuccess) return abandon_deferred(s, st, "result copy of a synchronous solve", he);
       bool flagged = false;
       if (s->fb_deferred) {
         const int *fl = reinterpret_cast<const int *>(s->hres_block + s->res_off[4]);
@@ -670,9 +714,15 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
       }
       if (flagged) {          // rare: the COD pass, then the results again
         rc = run_deferred_fallback(s, st);
-        if (rc != FCCQP_OK) return rc;
-        HIP_TRY(s, hipMemcpyAsync(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(s, hipStreamSynchronize(st));
+        if (rc != FCCQP_OK) {
+          const std::string msg = s->err;
+          (void)abandon_deferred(s, st, "fallback pass of a synchronous solve", hipSuccess);
+          s->err = msg;
+          return rc;
+        }
+        he = hipMemcpyAsync(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        if (he != hipSuccess) return abandon_deferred(s, st, "result copy behind the fallback pass", he);
       }
       s->fb_deferred = false;
       s->hres_fresh = true;
@@ -935,6 +985,23 @@ int fccqp_last_kernel_ms(fccqp_solver *s, float *ms) {
   if (!s->timed) return fail(s, FCCQP_ERR_UNSUPPORTED, "kernel timing is switched off (fccqp_set_kernel_timing)");
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return FCCQP_OK;
+}
+
+int fccqp_last_timing(fccqp_solver *s, float *ms, int *measured_by) {
+  if (!s || !ms || !measured_by) return FCCQP_ERR_INVALID_ARG;
+  if (!s->solved) return fail(s, FCCQP_ERR_NOT_SOLVED, "no solve has been run");
+  DeviceGuard g(s->device);
+  *ms = 0.f;
+  *measured_by = FCCQP_TIMING_NONE;
+  if (s->quiesced) {
+    *ms = s->host_device_ms;
+    *measured_by = FCCQP_TIMING_HOST_CLOCK;
+  } else if (s->timed) {
+    HIP_TRY(s, hipEventSynchronize(s->ev1));
+    HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
+    *measured_by = FCCQP_TIMING_DEVICE_EVENTS;
+  }
   return FCCQP_OK;
 }
 

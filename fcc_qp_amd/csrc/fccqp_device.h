@@ -149,6 +149,7 @@ constexpr int kFlagPresolveNumerical = 2;
 constexpr int kFlagAdmmNumerical = 4;
 constexpr int kFlagEqualityOnly = 8;
 constexpr int kFlagPresolveCod = 16;
+constexpr int kFlagEqResidual = 32;
 
 // ---- generic kernel (fccqp_generic.hip) -----------------------------------------------------
 // Largest KKT size N = n + m the generic kernel handles (8 register slots x 64 lanes; the reference's
@@ -170,6 +171,12 @@ hipError_t launch_generic_list(const KernelArgs &a, size_t lds_limit, int blocks
 // fp32-storage entry points)
 hipError_t launch_widen5(const float *const src[5], double *const dst[5], const size_t count[5],
                          hipStream_t stream);
+
+// ---- self-check behind a solve (fccqp_check.hip): raises kFlagEqResidual on every instance whose z is not finite or
+// violates A_eq z = b_eq by more than `tol` relative to the terms of the row (a.A / a.b_eq: the solve's inputs, a.x: z)
+hipError_t launch_eq_residual_check(const KernelArgs &a, hipStream_t stream, bool qa_f32, double tol);
+// shapes whose solves are always checked (the global-workspace instantiations of the generic kernel beyond this size)
+constexpr int kSelfCheckAboveN = 256;
 
 // ---- presolve fallback workspace (fccqp_cod_impl.h) ---------------------------------------------
 long long cod_workspace_doubles_host(int n, int m);

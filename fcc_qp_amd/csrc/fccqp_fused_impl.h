@@ -218,8 +218,11 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
   const double rs = fast_rsqrt(__builtin_fmax(nxy2, DBL_MIN));
   const double nxy = nxy2 * rs;
   const bool inside = mu * fz >= nxy;                   // :10-12
-  const bool polar = fz < -mu * nxy;                    // :15-17
-  const double t = fma(mu, nxy, fz) * kc;               // :20-23, see above
+  // :15-17, f_z < -mu |f_xy|, read off the numerator of t (one rounding instead of the product's: the two differ
+  // only where f_z + mu |f_xy| vanishes to the last bit, and there the other branch returns t dir = O(1e-16) |f|)
+  const double tnum = fma(mu, nxy, fz);
+  const bool polar = tnum < 0.0;
+  const double t = tnum * kc;                           // :20-23, see above
   const double dir = select_lanes(z_lanes, 1.0, rs * v);   // (VOP3 select on the loop-invariant lane mask of the z components)
   // zero ray (f_z == 0): Eigen's normalize() no-op -> 0, like the polar cone.  Straight-line VOP3 selects: whether the
   // backend makes this a branch around the outside-the-cone work or two VOP2 selects on VCC changed from build to build
@@ -1202,6 +1205,61 @@ __device__ __forceinline__ void dpp_matvec(double (&acc)[kMvAcc], const double (
   }
 }
 
+// The same mat-vec with TWO 16-column blocks per asm statement (the one-wave kernel's ADMM loop): between two asm
+// statements that touch the same accumulator the backend puts an `s_nop 0`, which costs this lone wave a whole issue slot
+// like any other instruction -- four statements per iteration cost three of them, two statements cost one (the
+// `s_waitcnt` for the second pair of w copies sits between the two).  Operands by name: m<B>_<K> = entry K of block B.
+#define FCCQP_MVF(B, K) "v_fmac_f64_dpp %[acc], %[w" #B "], %[m" #B "_" #K "] row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n\t"
+#define FCCQP_MV1(B) FCCQP_MVF(B, 0)
+#define FCCQP_MV2(B) FCCQP_MV1(B) FCCQP_MVF(B, 1)
+#define FCCQP_MV3(B) FCCQP_MV2(B) FCCQP_MVF(B, 2)
+#define FCCQP_MV4(B) FCCQP_MV3(B) FCCQP_MVF(B, 3)
+#define FCCQP_MV5(B) FCCQP_MV4(B) FCCQP_MVF(B, 4)
+#define FCCQP_MV6(B) FCCQP_MV5(B) FCCQP_MVF(B, 5)
+#define FCCQP_MV7(B) FCCQP_MV6(B) FCCQP_MVF(B, 6)
+#define FCCQP_MV8(B) FCCQP_MV7(B) FCCQP_MVF(B, 7)
+#define FCCQP_MV9(B) FCCQP_MV8(B) FCCQP_MVF(B, 8)
+#define FCCQP_MV10(B) FCCQP_MV9(B) FCCQP_MVF(B, 9)
+#define FCCQP_MV11(B) FCCQP_MV10(B) FCCQP_MVF(B, 10)
+#define FCCQP_MV12(B) FCCQP_MV11(B) FCCQP_MVF(B, 11)
+#define FCCQP_MV13(B) FCCQP_MV12(B) FCCQP_MVF(B, 12)
+#define FCCQP_MV14(B) FCCQP_MV13(B) FCCQP_MVF(B, 13)
+#define FCCQP_MV15(B) FCCQP_MV14(B) FCCQP_MVF(B, 14)
+#define FCCQP_MV16(B) FCCQP_MV15(B) FCCQP_MVF(B, 15)
+#define FCCQP_MVOPS(B, A) [m##B##_0] "v"(A[0]), [m##B##_1] "v"(A[1]), [m##B##_2] "v"(A[2]), [m##B##_3] "v"(A[3]), [m##B##_4] "v"(A[4]), [m##B##_5] "v"(A[5]), [m##B##_6] "v"(A[6]), [m##B##_7] "v"(A[7]), [m##B##_8] "v"(A[8]), [m##B##_9] "v"(A[9]), [m##B##_10] "v"(A[10]), [m##B##_11] "v"(A[11]), [m##B##_12] "v"(A[12]), [m##B##_13] "v"(A[13]), [m##B##_14] "v"(A[14]), [m##B##_15] "v"(A[15])
+#define FCCQP_MV_SINGLE(L) asm(FCCQP_MV##L(0) : [acc] "+v"(acc) : [w0] "v"(w0), FCCQP_MVOPS(0, m0))
+#define FCCQP_MV_PAIR(L) asm(FCCQP_MV16(0) FCCQP_MV##L(1) : [acc] "+v"(acc) : [w0] "v"(w0), [w1] "v"(w1), FCCQP_MVOPS(0, m0), FCCQP_MVOPS(1, m1))
+#define FCCQP_MV_DISPATCH(STMT) \
+  if constexpr (L == 16) STMT(16); else if constexpr (L == 15) STMT(15); else if constexpr (L == 14) STMT(14); \
+  else if constexpr (L == 13) STMT(13); else if constexpr (L == 12) STMT(12); else if constexpr (L == 11) STMT(11); \
+  else if constexpr (L == 10) STMT(10); else if constexpr (L == 9) STMT(9); else if constexpr (L == 8) STMT(8); \
+  else if constexpr (L == 7) STMT(7); else if constexpr (L == 6) STMT(6); else if constexpr (L == 5) STMT(5); \
+  else if constexpr (L == 4) STMT(4); else if constexpr (L == 3) STMT(3); else if constexpr (L == 2) STMT(2); \
+  else STMT(1)
+// blocks Q and Q + 1 (block Q whole, block Q + 1 with L columns), or -- the last of an odd number -- block Q alone
+template <int Q, int NN, int NQ>
+__device__ __forceinline__ void dpp_matvec_pairs(double &acc, const double (&Wq)[NQ], const double (&Mrow)[NN]) {
+  if constexpr (Q + 1 < NQ) {
+    constexpr int L = (NN - 16 * (Q + 1) < 16) ? NN - 16 * (Q + 1) : 16;
+    double m0[16], m1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      m0[i] = Mrow[16 * Q + i];
+      m1[i] = Mrow[(16 * (Q + 1) + i < NN) ? 16 * (Q + 1) + i : NN - 1];      // (past L: never named by an instruction)
+    }
+    const double w0 = Wq[Q], w1 = Wq[Q + 1];
+    FCCQP_MV_DISPATCH(FCCQP_MV_PAIR);
+    dpp_matvec_pairs<Q + 2, NN, NQ>(acc, Wq, Mrow);
+  } else if constexpr (Q < NQ) {
+    constexpr int L = (NN - 16 * Q < 16) ? NN - 16 * Q : 16;
+    double m0[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m0[i] = Mrow[(16 * Q + i < NN) ? 16 * Q + i : NN - 1];
+    const double w0 = Wq[Q];
+    FCCQP_MV_DISPATCH(FCCQP_MV_SINGLE);
+  }
+}
+
 // forces v[J .. NN) into (arch) VGPRs at this point of the program, ten at a time
 template <int J, int NN>
 __device__ __forceinline__ void pin_vgprs(double (&v)[NN]) {
@@ -1316,12 +1374,12 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
     int iter = 0, bound;
 #pragma nounroll
     do {
-      double acc[kMvAcc] = {xc_v, 0.0, 0.0, 0.0};
       // (the DPP read of a VGPR needs two wait states after a VALU write of it.  Wq comes straight from the LDS
       // reads and the s_waitcnt sits in between; tests/test_code_objects.py fails on a build where the
       // compiler puts a copy there.  An `s_nop 1` pinned here used to cost 16 cycles per iteration.)
-      dpp_matvec<0, n, NQ>(acc, Wq, Mrow);
-      x = mv_total(acc);
+      double acc = xc_v;
+      dpp_matvec_pairs<0, n, NQ>(acc, Wq, Mrow);
+      x = acc;
       // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in the first three lanes of this
       // lane's 16-lane row (or quad, Shape::kRowContacts): three DPP broadcasts, no LDS round trip
       const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused
@@ -1333,8 +1391,11 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
       // and the write-back all select on the lane's kind.
       {
         const double v = x + mux;
-        const double tt = min2(v, vub);   // std::min(x(i), ub(i))   constraint_utils.cpp:43
-        xbar = max2(tt, vlb);             // std::max(., lb(i))
+        // std::max(std::min(x(i), ub(i)), lb(i)), constraint_utils.cpp:43, as v_min_f64 / v_max_f64: the same value
+        // for every finite x (also for lb > ub, and a NaN bound is ignored by both), one instruction each instead
+        // of a compare and two selects; only a NaN x -- which the reference carries into x_bar -- is clamped here
+        const double tt = __builtin_fmin(v, vub);
+        xbar = __builtin_fmax(tt, vlb);
         xr = x - xbar;                    // :95
         mux += xr;                        // :101
       }

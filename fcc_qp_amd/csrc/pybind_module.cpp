@@ -270,6 +270,19 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def("Synchronize", &FCCQPBatch::Synchronize, py::call_guard<py::gil_scoped_release>())
       .def("GetSolution", &FCCQPBatch::GetSolution)
       .def("LastKernelMilliseconds", &FCCQPBatch::LastKernelMilliseconds)
+      .def("LastTiming",
+           [](const FCCQPBatch &self) {
+             const auto t = self.LastTiming();
+             const char *by = t.second == FCCQP_TIMING_DEVICE_EVENTS ? "device_events"
+                              : (t.second == FCCQP_TIMING_HOST_CLOCK ? "host_clock" : "none");
+             return py::make_tuple(t.first, std::string(by));
+           },
+           "(milliseconds, how they were measured) of the last solve: 'device_events' (HIP events around the launches), "
+           "'host_clock' (small synchronous host-pointer solves: launch to completion, results copied) or 'none' "
+           "(kernel timing switched off)")
+      .def("set_self_check", &FCCQPBatch::set_self_check, py::arg("enabled"),
+           "re-check A_eq z = b_eq behind every solve (flag FLAG_EQ_RESIDUAL); default: on for num_vars + "
+           "num_equality_constraints > 256")
       .def("AlgorithmicBytes", &FCCQPBatch::AlgorithmicBytes)
       .def("device_pointers",
            [](FCCQPBatch &self) {
@@ -340,4 +353,5 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
   m.attr("FLAG_ADMM_NUMERICAL") = (int)FCCQP_FLAG_ADMM_NUMERICAL;
   m.attr("FLAG_EQUALITY_ONLY") = (int)FCCQP_FLAG_EQUALITY_ONLY;
   m.attr("FLAG_PRESOLVE_COD") = (int)FCCQP_FLAG_PRESOLVE_COD;
+  m.attr("FLAG_EQ_RESIDUAL") = (int)FCCQP_FLAG_EQ_RESIDUAL;
 }

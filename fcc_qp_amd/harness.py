@@ -118,7 +118,7 @@ def run_chains(logs: Sequence[Sequence[Dict[str, np.ndarray]]], shape: P.Shape =
         solver.set_warm_start(t > 0)                                     # fcc_qp_test.py:87, for every chain
         solver.Solve(*B.arrays())
         sol = solver.GetSolution()
-        kernel_ms.append(solver.LastKernelMilliseconds())
+        kernel_ms.append(solver.LastTiming())        # (ms, 'device_events' | 'host_clock' | 'none')
         for k, l in enumerate(logs):
             if t < len(l):
                 zs[k].append(np.array(sol.z[k], copy=True))
@@ -127,8 +127,14 @@ def run_chains(logs: Sequence[Sequence[Dict[str, np.ndarray]]], shape: P.Shape =
     reports = []
     for k, l in enumerate(logs):
         rep = _series(np.vstack(zs[k]), details[k], shape)
+        # one kind of measurement per report: small batches take the low-latency path, whose time is the host's
+        # clock from launch to completion (results copied), larger ones a HIP event pair around the launches
+        kinds = sorted({by for _, by in kernel_ms})
+        by = kinds[0] if len(kinds) == 1 else "mixed"
+        ms = [m for m, b in kernel_ms if b != "none"]
         rep.update(mode=f"warm-start chain {k} of {K} advanced in lock-step", count=len(l), wall_seconds=wall,
-                   options=options, kernel_ms_per_step=float(np.mean(kernel_ms)))
+                   options=options, kernel_ms_per_step=(float(np.mean(ms)) if ms and by != "mixed" else None),
+                   kernel_ms_measured_by=by)
         reports.append(rep)
     return reports
 

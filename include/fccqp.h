@@ -64,8 +64,12 @@ enum {
                                            (fallback disabled) z is NOT comparable              */
   FCCQP_FLAG_ADMM_NUMERICAL = 4,        /* ADMM LDL^T met a zero / non-finite pivot              */
   FCCQP_FLAG_EQUALITY_ONLY = 8,         /* nc == 0 and all bounds infinite: no ADMM (:132-133)   */
-  FCCQP_FLAG_PRESOLVE_COD = 16          /* x0 came from the device COD fallback (min-norm least
+  FCCQP_FLAG_PRESOLVE_COD = 16,         /* x0 came from the device COD fallback (min-norm least
                                            squares, fcc_qp.cpp:165,176): z IS comparable again   */
+  FCCQP_FLAG_EQ_RESIDUAL = 32           /* self-check (fccqp_set_self_check): the returned z is not finite, or
+                                           |A_eq z - b_eq| exceeds 1e-6 of the terms of some row.  Every primal
+                                           iterate is the head of a KKT solve (fcc_qp.cpp:86-87), so this never
+                                           happens for consistent equality rows unless the solve went wrong      */
 };
 
 /* kernel selection */
@@ -143,6 +147,11 @@ int fccqp_set_presolve_fallback(fccqp_solver *s, int enabled);
  * and solve_time of a device-pointer solve is 0.  (No counterpart in the reference, whose solve_time is a host
  * chrono pair, src/fcc_qp.cpp:115,188.) */
 int fccqp_set_kernel_timing(fccqp_solver *s, int enabled);
+/* Self-check behind every solve: one more small launch that re-computes A_eq z - b_eq from the solve's inputs and
+ * raises FCCQP_FLAG_EQ_RESIDUAL on the instances that fail it.  Default: on for num_vars + num_equality_constraints
+ * > 256 (the generic kernel's global-workspace instantiations), off otherwise.  The
+ * reference has no counterpart: it reports nothing about the quality of a solve beyond n_iter. */
+int fccqp_set_self_check(fccqp_solver *s, int enabled);
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use);
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
                     int *lambda_c_start, int *batch, int *device);
@@ -236,6 +245,14 @@ int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x,
  * of such a solve -- and reports the host-measured time from the launch to the completion of the device
  * work instead (a few microseconds more than the kernel itself). */
 int fccqp_last_kernel_ms(fccqp_solver *s, float *ms);
+/* The same figure together with HOW it was measured, so that a caller does not average two different things:
+ *   FCCQP_TIMING_DEVICE_EVENTS  HIP events around the solve's launches on their stream (device time);
+ *   FCCQP_TIMING_HOST_CLOCK     small synchronous host-pointer solves record no events (each costs ~5 us of stream
+ *                               time): host clock from the launch to the completion of the device work, i.e. launch
+ *                               latency, kernel, the copy of the results and, if an instance was flagged, the COD pass;
+ *   FCCQP_TIMING_NONE           nothing was measured (fccqp_set_kernel_timing(s, 0)); *ms = 0. */
+enum { FCCQP_TIMING_NONE = 0, FCCQP_TIMING_DEVICE_EVENTS = 1, FCCQP_TIMING_HOST_CLOCK = 2 };
+int fccqp_last_timing(fccqp_solver *s, float *ms, int *measured_by);
 /* Mean device time (seconds) the instances of the last solve spent per phase (fused kernel; the generic
  * kernel fills the slots it has): out[0] issue of the matrix loads (assembly on the generic kernel),
  * [1] factorisations (K_rho with the fused forward solve, and W), [2] presolve (W's factorisation and the

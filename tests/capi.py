@@ -14,7 +14,8 @@ HEADER = os.path.join(ROOT, "include", "fccqp.h")
 
 OK, ERR_INVALID_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_FRICTION, ERR_NOT_SOLVED, ERR_UNSUPPORTED = range(9)
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_COOP = 0, 1, 2, 3, 4
-FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD = 1, 2, 4, 8, 16
+FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD, FLAG_EQ_RESIDUAL = 1, 2, 4, 8, 16, 32
+TIMING_NONE, TIMING_DEVICE_EVENTS, TIMING_HOST_CLOCK = 0, 1, 2
 
 
 class Options(C.Structure):
@@ -60,6 +61,9 @@ def lib():
         L.fccqp_set_kernel.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_set_presolve_fallback.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        if hasattr(L, "fccqp_set_self_check"):          # (older builds under FCCQP_LIB_PATH, tools/ab_bench.py)
+            L.fccqp_set_self_check.argtypes = [C.c_void_p, C.c_int]
+            L.fccqp_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.fccqp_get_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.fccqp_solve.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.fccqp_solve_device.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]
@@ -165,6 +169,14 @@ class Solver:
         ms = C.c_float()
         self._ck(self.L.fccqp_last_kernel_ms(self.h, C.byref(ms)), "last_kernel_ms")
         return ms.value
+
+    def last_timing(self):
+        ms, by = C.c_float(), C.c_int()
+        self._ck(self.L.fccqp_last_timing(self.h, C.byref(ms), C.byref(by)), "last_timing")
+        return ms.value, by.value
+
+    def set_self_check(self, on):
+        self._ck(self.L.fccqp_set_self_check(self.h, int(bool(on))), "set_self_check")
 
     def phase_seconds(self):
         out = (C.c_double * 8)()

@@ -50,6 +50,7 @@ int fccqp_set_warm_start(fccqp_solver *s, int w) { s->warm = w; return FCCQP_OK;
 int fccqp_set_kernel(fccqp_solver *s, int k) { s->kernel = k; return FCCQP_OK; }
 int fccqp_set_presolve_fallback(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_set_kernel_timing(fccqp_solver *, int) { return FCCQP_OK; }
+int fccqp_set_self_check(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_get_kernel(const fccqp_solver *s, int *k) { *k = s->kernel; return FCCQP_OK; }
 int fccqp_get_shape(const fccqp_solver *s, int *n, int *m, int *nc, int *st, int *b, int *d) {
   if (n) *n = s->n; if (m) *m = s->m; if (nc) *nc = s->nc; if (st) *st = s->s; if (b) *b = s->batch; if (d) *d = s->device;
@@ -101,6 +102,7 @@ int fccqp_get_solution_device(fccqp_solver *, const double **, const int **, con
 int fccqp_get_state(fccqp_solver *, double *, double *, double *) { return FCCQP_OK; }
 int fccqp_set_state(fccqp_solver *, const double *, const double *, const double *) { return FCCQP_OK; }
 int fccqp_last_kernel_ms(fccqp_solver *s, float *ms) { *ms = 1.0f + s->device; return FCCQP_OK; }
+int fccqp_last_timing(fccqp_solver *s, float *ms, int *by) { *ms = 1.0f + s->device; *by = FCCQP_TIMING_DEVICE_EVENTS; return FCCQP_OK; }
 int fccqp_phase_seconds(fccqp_solver *, double out[8]) { std::memset(out, 0, 64); return FCCQP_OK; }
 int fccqp_algorithmic_bytes(const fccqp_solver *, long long *b) { *b = 0; return FCCQP_OK; }
 int fccqp_debug_read_workspace(fccqp_solver *, double *, long long, long long *a) { if (a) *a = 0; return FCCQP_OK; }

@@ -238,3 +238,26 @@ def test_admm_loop_has_no_vop2_selects(objects):
             assert sum(1 for mn, ops in window if mn.startswith("v_fmac_f64") and "row_newbcast" in ops) >= 60
             seen += 1
     assert seen >= 2
+
+
+def test_global_workspace_kernels_make_no_real_calls(objects):
+    """The generic kernel's global-workspace instantiations (MAT_IN_LDS = false: 198 < N <= 512, among them the
+    eight-slot kernel for N > 256) must not contain a real function call.  Built WITH calls -- 256 VGPRs + 256 AGPRs,
+    callee-saved registers parked in AGPRs, scratch frames -- the eight-slot kernel returned wrong, run-to-run
+    different z on MI355X while the same source built with `-mllvm -amdgpu-function-calls=false` was exact
+    (fcc_qp_amd/build.py).  A toolchain or flag change that brings the calls back must fail
+    here, on the CPU, not as silent wrong answers on a GPU.  (`s_setpc_b64` alone is a long branch and is allowed;
+    `s_swappc_b64` is the call.  The LDS-resident instantiations still call the noinline G build: they are covered
+    by the parity tests on every box and have never failed.)"""
+    seen = 0
+    for _, meta, dis in objects:
+        for name, rec in meta.items():
+            if "generic_kernel" not in name or "Lb0E" not in name:      # generic_kernel<SLOTS, false, ...>
+                continue
+            seen += 1
+            body = dis.get(name, [])
+            assert body, f"{name}: not in the disassembly"
+            calls = [ops for mn, ops in body if mn in ("s_swappc_b64", "s_call_b64")]
+            assert not calls, f"{name}: {len(calls)} real function calls"
+            assert not rec.get("uses_dynamic_stack", False), f"{name}: dynamic stack"
+    assert seen >= 8, f"only {seen} global-workspace instantiations found"

@@ -105,6 +105,7 @@ def _random_qp(rng, n, m, nc, s, finite_bounds=True):
                                   (12, 8, 6, 3),        # fused: identity-padded last tile row (N = 20), no border
                                   (32, 14, 6, 20),      # fused: n a multiple of 16, padded (N = 46)
                                   (32, 18, 6, 20),      # fused: n a multiple of 16, two bordered rows (N = 50)
+                                  (24, 6, 15, 4),       # fused: five contacts -- the quad lane map of the ADMM loop (N = 30)
                                   (20, 20, 0, 0), (33, 9, 9, 24),
                                   (64, 0, 12, 10), (65, 63, 3, 0), (100, 40, 30, 50), (130, 70, 24, 100),
                                   (129, 40, 9, 120),    # 3 slots in LDS, n > 128: four waves, sweeps only
@@ -361,8 +362,8 @@ def _as_f32_batch(B):
 
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("dims", [P.WALKING.ctor_args, P.LARGE.ctor_args, (12, 5, 6, 3), (12, 8, 6, 3), (32, 14, 6, 20),
-                                  (32, 18, 6, 20), (33, 9, 9, 24)],
-                         ids=["walking", "large", "mini", "padded", "n32-padded", "n32-border", "odd"])
+                                  (32, 18, 6, 20), (24, 6, 15, 4), (33, 9, 9, 24)],
+                         ids=["walking", "large", "mini", "padded", "n32-padded", "n32-border", "five-contacts", "odd"])
 def test_fp32_storage_inputs_equal_fp64_path_on_widened_values(oracle, dims, kernel):
     """fccqp_solve_f32 (BASELINE configs[2]): float arrays, widened on load, fp64 arithmetic --
     bit for bit the result of fccqp_solve on the widened values, and within tolerance of the oracle."""

@@ -84,7 +84,7 @@ def test_split_with_instances_that_leave_for_the_cod_pass(oracle, fallback):
         assert all(bool(f & CAPI.FLAG_PRESOLVE_COD) == (i in (2, 7, 8)) for i, f in enumerate(two[0][2]))
 
 
-@pytest.mark.parametrize("dims", [(12, 5, 6, 3), (12, 8, 6, 3), (32, 14, 6, 20), (32, 18, 6, 20), (12, 7, 6, 3)])
+@pytest.mark.parametrize("dims", [(12, 5, 6, 3), (12, 8, 6, 3), (32, 14, 6, 20), (32, 18, 6, 20), (12, 7, 6, 3), (24, 6, 15, 4)])
 def test_split_on_the_other_compiled_shapes(oracle, dims):
     rng = np.random.default_rng(sum(dims))
     n, m, nc, s = dims

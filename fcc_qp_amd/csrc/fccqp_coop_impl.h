@@ -53,6 +53,54 @@ using lds_i32 = __attribute__((address_space(3))) int;
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// ---- ADMM layout for n > 64 ("row split"): FOUR ADMM waves, each owning a quarter of the variables (32 slots, one
+// per lane of the lower half of the wave, mirrored in the upper half); the two 32-lane halves of a wave split the
+// COLUMNS of rho G: the lower half multiplies the variables of waves 0 and 1, the upper half those of waves 2 and 3,
+// and one v_permlane32_swap pair adds the halves.  Against splitting the columns over waves (the layout of the
+// shapes with n <= 64, and of this one through round 3) no partial sum crosses a wave any more: ONE exchange of w and
+// ONE barrier per iteration instead of two of each.  Slot q of wave a is position p = 32 a + q.  Up to two contacts
+// per wave, contact j of the wave in slots 16 j .. 16 j + 2 (one contact per 16-lane row: a force component reaches
+// its lanes by one v_mov_b64_dpp); the other variables fill the remaining slots in increasing order, the waves'
+// shares as even as they come.  A struct of its own: Shape takes constants from its functions.
+template <int N_VARS, int NC, int LC_START>
+struct RowSplit {
+  static constexpr int n = N_VARS, nc = NC, s = LC_START, kContacts = NC / 3;
+  static constexpr int cap(int a) { return n / 4 + ((a < n % 4) ? 1 : 0); }
+  static constexpr int wave_contacts(int a) { return (kContacts - 2 * a >= 2) ? 2 : ((kContacts - 2 * a >= 1) ? 1 : 0); }
+  static constexpr int wave_others(int a) { return cap(a) - 3 * wave_contacts(a); }
+  static constexpr int others_before(int a) {
+    int k = 0;
+    for (int q = 0; q < a; ++q) k += wave_others(q);
+    return k;
+  }
+  static constexpr bool slot_is_cone(int a, int q) { return (q >> 4) < wave_contacts(a) && (q & 15) < 3; }
+  // slot q of wave a -> variable, -1: none (no loops: the kernel evaluates it per lane with `a` a compile-time constant)
+  static constexpr int slot_variable(int a, int q) {
+    const int nca = wave_contacts(a), j = q >> 4, t = q & 15;
+    const int c0 = (nca >= 1) ? ((q < 3) ? q : 3) : 0;
+    const int c1 = (nca >= 2) ? ((q < 16) ? 0 : ((q - 16 < 3) ? q - 16 : 3)) : 0;
+    const int oi = q - c0 - c1;
+    const int k = others_before(a) + oi;
+    const int other = (oi < wave_others(a)) ? ((k < s) ? k : k + nc) : -1;
+    return (j < nca && t < 3) ? s + 3 * (2 * a + j) + t : other;
+  }
+  static constexpr int pos_variable(int p) { return slot_variable(p >> 5, p & 31); }
+  static constexpr int max_slot() {
+    int m = 0;
+    for (int p = 0; p < 128; ++p) if (pos_variable(p) >= 0 && (p & 31) > m) m = p & 31;
+    return m;
+  }
+  static constexpr bool every_variable_once() {
+    for (int v = 0; v < n; ++v) {
+      int hits = 0;
+      for (int p = 0; p < 128; ++p) hits += (pos_variable(p) == v) ? 1 : 0;
+      if (hits != 1) return false;
+    }
+    return true;
+  }
+  static constexpr bool fits() { return kContacts <= 8 && wave_others(0) >= 0 && wave_others(1) >= 0 && wave_others(2) >= 0 && wave_others(3) >= 0; }
+};
+
 template <int N_VARS, int N_EQ, int NC, int LC_START, int WAVES>
 struct Shape {
   static constexpr int n = N_VARS, m = N_EQ, nc = NC, s = LC_START, N = n + m, W = WAVES;
@@ -68,9 +116,16 @@ struct Shape {
   // redundant work.  The waves beyond RH * CSA leave the kernel in front of the loop.
   static constexpr int CSA = (RH * CS > 4) ? ((4 / RH > 1) ? 4 / RH : 1) : CS;
   static constexpr int kPos = 64 * RH;               // lane positions (one per variable, some unused)
+  // n > 64: the row-split ADMM layout (RowSplit above) -- four ADMM waves, rows over waves, columns over lane halves
+  static constexpr bool kRowSplit = RH == 2;
+  using RS = RowSplit<N_VARS, NC, LC_START>;
+  static constexpr int kRsOdd = kRowSplit ? RS::max_slot() - 15 : 1;     // FMAs of a block of slots 16 .. 31 (slots 0 .. 15: sixteen)
+  static constexpr int kRsLen = 2 * (16 + kRsOdd);                        // entries of rho G a lane holds
   static_assert(n >= 1 && n <= 128 && m >= 1, "two row halves at most");
   static_assert(W == 2 || W == 4 || W == 8, "waves per workgroup");
   static_assert(W % RH == 0 && CS >= 1 && CSA >= 1 && CSA <= CS && CSA <= NW, "every column split owns at least one 16-column block");
+  static_assert(!kRowSplit || (W >= 4 && RS::fits() && RS::every_variable_once() && kRsOdd >= 1 && kRsOdd <= 15),
+                "row-split ADMM layout: four ADMM waves, at most eight contacts, more than 64 variables, slot 31 of every wave free (it carries the exit word)");
   static_assert(nc % 3 == 0 && nc > 0 && s + nc <= n, "fcc_qp.cpp:32-33; shapes without contacts run on the generic kernel");
   static constexpr int kContacts = nc / 3;
   static_assert(4 * kContacts <= kPos, "one quad of lanes per contact");
@@ -97,7 +152,8 @@ struct Shape {
   static constexpr int kRhs = kRcp + 16 * NRB;                          // [-b; b_eq]; later x_c, x0
   static constexpr int kRhsLen = cmax(16 * NRB, kPos + 64);
   static constexpr int kRed = kRhs + kRhsLen;                           // end-of-solve reductions [RH][4]
-  static constexpr int kInts = kRed + 4 * RH;                           // int words: flags
+  static constexpr int kRed2 = kRed;                                    // ... row-split layout: [4 waves][4]
+  static constexpr int kInts = kRed + 16;                               // int words: flags
   static constexpr int kBig = (kInts + 16 + 1) & ~1;
   static constexpr int kTile = 256;                                     // doubles per published tile
   static constexpr int kVbufLen = 2 * NRB * kTile;                      // V_pj of two panels
@@ -108,7 +164,9 @@ struct Shape {
   // ADMM exchange: partial sums [2][CS][kPos] (by iteration parity), then w by variable (one copy, or one per wave when RH == 1), then the
   // per-iteration exit words
   static constexpr int kWv = 16 * NW + 16;                              // (+ a dummy slot for lanes without a variable)
-  static constexpr int kPart = 0, kWvOff = 2 * CS * kPos, kAdmmLen = kWvOff + ((RH == 1) ? W : 1) * kWv;
+  // (row split: w by position, [2][128] doubles by iteration parity)
+  static constexpr int kRsW = 0;
+  static constexpr int kPart = 0, kWvOff = 2 * CS * kPos, kAdmmLen = kRowSplit ? kRsW + 256 + 64 : kWvOff + ((RH == 1) ? W : 1) * kWv;
   static constexpr int kBigLen = cmax(cmax(kVbufLen, kYbufLen), cmax(cmax(kImage, kWfacLen), kAdmmLen));
   static constexpr int kLdsDoubles = kBig + kBigLen;
   static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS of one CU");
@@ -388,7 +446,8 @@ __device__ __forceinline__ void coop_gram(lds_f64 *L, const int lane, const doub
           if (J == cbd && c == n && row < n) xcv[row] = gv;
           if (J < NW) {
             const double unit = (I == J && row == c) ? 1.0 : 0.0;
-            Wt[I][J][r] = inside ? unit - g : unit;
+            if (interior) Wt[I][J][r] = unit - g;
+            else Wt[I][J][r] = select_lanes(__builtin_amdgcn_ballot_w64(inside), unit - g, unit);   // (VOP3 select)
           }
         }
       }
@@ -432,10 +491,16 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
     if (lane < 16 && col < kValid) {
       const int jcol = 16 * Pn + col, cb = SW::cbase(jcol);
       M[SW::kZeroFilled ? SW::kDinv + jcol : cb + jcol] = rmine;
+      // (above the diagonal: a dummy slot.  The address select written out as VOP3 on a ballot, as in the one-wave
+      // kernel: the compiler's `v_cmp -> VCC, s_nop 1, v_cndmask_b32_e32` costs 32 cycles per store on this -- serial --
+      // path, this 10; `colv`: hidden from CSE, or the masks are hoisted out of the panels and spilled)
+      int colv = col;
+      asm volatile("" : "+v"(colv));
+      const int below0 = (int)(M - L) + cb + 16 * Pn, dummy = SH::kSblk + colv;
 #pragma unroll
       for (int i = 1; i < kValid; ++i) {
-        lds_f64 *dst = (i > col) ? M + cb + 16 * Pn + i : Sblk + col;      // (above the diagonal: a dummy slot)
-        *dst = T[i] * rmine;
+        const int idx = select32_lanes(__builtin_amdgcn_ballot_w64(i > colv), below0 + i, dummy);
+        L[idx] = T[i] * rmine;
       }
     }
     if (bad && lane == 0) iflags[1] = 1;
@@ -584,6 +649,36 @@ __device__ __forceinline__ void solve_lds_slots(const lds_f64 *M, const int lane
   }
 }
 
+// ---- row-split ADMM layout (Shape::kRowSplit): the mat-vec of one lane half, ONE asm statement (fccqp_fused_impl.h:
+// a second statement costs a second s_waitcnt and an s_nop).  Blocks 0 and 2 are slots 0 .. 15 of the half's two
+// waves (sixteen FMAs each), blocks 1 and 3 their slots 16 .. 15 + L.  Mrow: [16 | L | 16 | L].
+#define FCCQP_MV_RS(L)                                                                                                \
+  asm(FCCQP_MV16(0) FCCQP_MV##L(1) FCCQP_MV16(2) FCCQP_MV##L(3)                                                       \
+      : [acc] "+v"(acc) : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), FCCQP_MVOPS(0, m0), FCCQP_MVOPS(1, m1), \
+        FCCQP_MVOPS(2, m2), FCCQP_MVOPS(3, m3))
+template <int L, int NN>
+__device__ __forceinline__ void rs_matvec(double &acc, const double (&Wq)[4], const double (&Mrow)[NN]) {
+  static_assert(NN == 2 * (16 + L) && L >= 1 && L <= 16, "[16 | L | 16 | L]");
+  double m0[16], m1[16], m2[16], m3[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    m0[i] = Mrow[i];
+    m1[i] = Mrow[16 + ((i < L) ? i : L - 1)];
+    m2[i] = Mrow[16 + L + i];
+    m3[i] = Mrow[32 + L + ((i < L) ? i : L - 1)];
+  }
+  const double w0 = Wq[0], w1 = Wq[1], w2 = Wq[2], w3 = Wq[3];
+  FCCQP_MV_DISPATCH(FCCQP_MV_RS);
+}
+// sum of the two 32-lane halves of a wave, in every lane: v_permlane32_swap of a register with itself leaves the lower
+// half's values in both halves of one result and the upper half's in the other
+__device__ __forceinline__ double add_lane_halves(const double v) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const v2u lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+  const v2u hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+  return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+
 // ---- the whole solve as seen by wave WV of the workgroup ------------------------------------------------------
 template <class SH, int WV, class TIN>
 __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, lds_f64 *L) {
@@ -603,15 +698,20 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   double *mux_s = a.mu_x + (size_t)inst * n;
   double *mulc_s = a.mu_lc + (size_t)inst * nc;
 
-  // ADMM role of this wave: row half h, column split c
-  constexpr int h = WV % RH, c = WV / RH;
-  const int pos = 64 * h + lane;
-  const int var = SH::pos_variable(pos);
+  // ADMM role of this wave.  n <= 64: row half h (always 0), column split c.  n > 64 (Shape::kRowSplit): waves 0 .. 3
+  // own 32 slots of variables each (lane & 31; both lane halves hold the slot's variable), the lane half picks the
+  // column half of rho G.
+  constexpr bool kRS = SH::kRowSplit;
+  using RS = typename SH::RS;
+  constexpr int h = kRS ? 0 : WV % RH, c = kRS ? 0 : WV / RH;
+  const int half = lane >> 5, slot = lane & 31;
+  const int pos = kRS ? 32 * (WV & 3) + slot : 64 * h + lane;
+  const int var = kRS ? RS::slot_variable(WV & 3, slot) : SH::pos_variable(pos);
   const bool isvar = var >= 0;
   const int vi = isvar ? var : 0;
-  const bool is_cone = ((pos >> 2) < SH::kContacts) && ((pos & 3) < 3);
-  const int cidx = is_cone ? (pos >> 2) : 0;
-  const int ccomp = is_cone ? (pos & 3) : 0;
+  const bool is_cone = kRS ? RS::slot_is_cone(WV & 3, slot) : (((pos >> 2) < SH::kContacts) && ((pos & 3) < 3));
+  const int cidx = is_cone ? (kRS ? 2 * (WV & 3) + (slot >> 4) : (pos >> 2)) : 0;
+  const int ccomp = is_cone ? (kRS ? (slot & 15) : (pos & 3)) : 0;
 
   const long long t_begin = wall_clock64();
   long long ticks = 0, ph_asm = 0, ph_p3 = 0, ph_solve = 0, ph_p4 = 0, ph_wfac = 0;
@@ -632,9 +732,9 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     if (lane < 16) iflags[lane] = 0;
   }
 
-  constexpr bool kAdmmWave = c < SH::CSA;            // (the others: q0 / q1 are placeholders, nothing is read)
-  constexpr int q0 = kAdmmWave ? SH::qlo(c) : 0, q1 = kAdmmWave ? SH::qlo(c + 1) : 1;
-  constexpr int col0 = 16 * q0, ncol = ((16 * q1 < n) ? 16 * q1 : n) - col0, NQL = q1 - q0;
+  constexpr bool kAdmmWave = kRS ? (WV < 4) : (c < SH::CSA);            // (the others: q0 / q1 are placeholders, nothing is read)
+  constexpr int q0 = (kAdmmWave && !kRS) ? SH::qlo(c) : 0, q1 = (kAdmmWave && !kRS) ? SH::qlo(c + 1) : 1;
+  constexpr int col0 = 16 * q0, ncol = kRS ? SH::kRsLen : ((16 * q1 < n) ? 16 * q1 : n) - col0, NQL = kRS ? 4 : q1 - q0;
   double Mrow[ncol];
   double xc = 0.0, x = 0.0;
   long long t4;
@@ -658,7 +758,20 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     {
       const lds_f64 *img = L + SH::kBig;
       xc = isvar ? rhs[vi] : 0.0;
-      if constexpr (kAdmmWave) {
+      if constexpr (kAdmmWave && kRS) {
+        // entry e of block k: the variable in slot 16 (k & 1) + e of wave 2 half + (k >> 1) -- its column of this row
+        constexpr int LO = SH::kRsOdd;
+        static_for<0, SH::kRsLen>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          constexpr int k = (e < 16) ? 0 : ((e < 16 + LO) ? 1 : ((e < 32 + LO) ? 2 : 3));
+          constexpr int i = e - ((k == 0) ? 0 : ((k == 1) ? 16 : ((k == 2) ? 16 + LO : 32 + LO)));
+          constexpr int p0 = 32 * (k >> 1) + 16 * (k & 1) + i;                  // position in the lower half's columns
+          constexpr int v0 = RS::pos_variable(p0), v1 = RS::pos_variable(64 + p0);
+          const int cv = half ? v1 : v0;
+          const double g = img[vi * n + ((cv >= 0) ? cv : 0)];
+          Mrow[e] = (isvar && cv >= 0) ? g : 0.0;
+        });
+      } else if constexpr (kAdmmWave) {
 #pragma unroll
         for (int j = 0; j < ncol; ++j) Mrow[j] = isvar ? img[vi * n + col0 + j] : 0.0;
       }
@@ -707,6 +820,176 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------------------------------
   // (a wave without a column split is done: s_barrier counts the surviving waves of the workgroup only)
   if constexpr (!kAdmmWave) return;
+  if constexpr (kRS) {
+    // ---- row-split layout (Shape::kRowSplit, RowSplit): per iteration ONE LDS exchange (w by position, double-
+    // buffered by iteration parity) and ONE barrier; the per-wave exit words ride on the same barrier -------------------
+    // w by position, [2][128] doubles by iteration parity.  Slot 31 of every wave holds no variable (static_assert in
+    // Shape): it carries the wave's exit word -- 1.0 while some residual of the wave is above its eps -- to the other
+    // waves with the same store, barrier and loads that carry w (a word of its own cost a masked store, a 16-byte
+    // load, three ORs and a v_readfirstlane per iteration).
+    lds_f64 *const wbuf = L + SH::kBig + SH::kRsW;
+    lds_f64 *const w_store[2] = {wbuf + pos, wbuf + 128 + pos};                                       // this slot's w
+    const lds_f64 *const w_fetch[2] = {wbuf + 64 * half + (lane & 15), wbuf + 128 + 64 * half + (lane & 15)};   // + 16 q
+    const double vlb = isvar ? lbp[vi] : -HUGE_VAL;
+    const double vub = isvar ? ubp[vi] : HUGE_VAL;
+    const double vmu = is_cone ? mup[cidx] : 0.0;
+    double mux = 0.0, mulc = 0.0;
+    if (a.warm_start) {
+      mux = isvar ? mux_s[vi] : 0.0;
+      mulc = is_cone ? mulc_s[is_cone ? vi - s0 : 0] : 0.0;
+    }
+    double xbar = x, lcbar = x;                        // :74-75
+    double xr = 0.0, lr = 0.0;
+    const double vkc = cone_lane_constant(vmu, ccomp == 2);
+    const double dir_xy = (ccomp == 2) ? 0.0 : 1.0, dir_z = (ccomp == 2) ? 1.0 : 0.0;
+    const double eps_b = a.eps_bound, eps_f = a.eps_fcone;
+    const double xc_half = half ? 0.0 : xc;            // x_c rides in the lower half's accumulator
+    const int max_iter = a.max_iter;
+    int n_iter = max_iter;                             // :78
+    double Wq[4];
+    wg_barrier();                                      // everyone has x (and is done with the factor of W): the exchange area is free
+    const unsigned long long cone_lanes = __builtin_amdgcn_ballot_w64(is_cone),
+                             flag_lanes = __builtin_amdgcn_ballot_w64(slot == 31),          // where the exit words travel ...
+                             flag_cols = __builtin_amdgcn_ballot_w64((lane & 15) == 15);   // ... and arrive (Wq[1], Wq[3])
+    // (the exit word goes out by a store of its own BEHIND w's -- every lane stores, the lanes of slot 31 to the slot,
+    // the others to a word of their own behind the copies: no EXEC round trip --, so that w does not wait for the
+    // compare-and-mask chain of the exit test)
+    lds_f64 *const f_store[2] = {(slot == 31) ? w_store[0] : wbuf + 256 + lane, (slot == 31) ? w_store[1] : wbuf + 256 + lane};
+    auto publish_w = [&](const int par) {
+      // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82).  Both lane halves hold
+      // the slot's value and store it to the same word.  (A lane without a variable has w == 0.)
+      *w_store[par] = select_lanes(cone_lanes, lcbar - mulc, xbar - mux);
+    };
+    auto publish_flag = [&](const int par, const bool wave_fails) { *f_store[par] = wave_fails ? 1.0 : 0.0; };
+    auto fetch_w = [&](const int par) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Wq[q] = w_fetch[par][16 * q];
+    };
+    if (max_iter > 0) {
+      publish_w(0);
+      lds_fence();
+      publish_flag(0, true);                           // ("not converged": there is no iteration -1 to leave after)
+      wg_barrier();
+      fetch_w(0);
+      lds_fence();
+    }
+    // lane 15 of every 16-lane row of Wq[1] / Wq[3]: slot 31 of the two waves whose columns this lane half multiplies
+    auto everyone_passed = [&]() {
+      return ((__builtin_amdgcn_ballot_w64(Wq[1] != 0.0) | __builtin_amdgcn_ballot_w64(Wq[3] != 0.0)) & flag_cols) == 0;
+    };
+    // One iteration, publishing to / fetching from the copies of parity PAR.  The exit test of the PREVIOUS iteration
+    // (:105-109) is evaluated behind this one's mat-vec: its words arrive with w, and looking at them first would put
+    // their compare-and-branch chain between the loads and the FMAs that wait for the same loads anyway; an iteration
+    // that finds the previous one converged has only computed an accumulator it throws away.  true: leave.
+    auto iteration = [&](auto parc) -> bool {
+      constexpr int PAR = decltype(parc)::value;
+      double acc = xc_half;
+      rs_matvec<SH::kRsOdd>(acc, Wq, Mrow);
+      if (everyone_passed()) return true;
+      x = add_lane_halves(acc);
+      const double xm = x + mulc;
+      {
+        // std::max(std::min(x(i), ub(i)), lb(i)), constraint_utils.cpp:43, as v_min_f64 / v_max_f64 (see the one-wave
+        // kernel; written as asm: the builtins re-canonicalise the loop-invariant bounds in every iteration here)
+        double tt;
+        asm("v_min_f64 %0, %1, %2" : "=v"(tt) : "v"(x + mux), "v"(vub));
+        asm("v_max_f64 %0, %1, %2" : "=v"(xbar) : "v"(tt), "v"(vlb));
+        xr = x - xbar;                    // :95
+        mux += xr;                        // :101
+      }
+      {
+        const double cfx = contact_bcast<0, true>(xm), cfy = contact_bcast<1, true>(xm), cfz = contact_bcast<2, true>(xm);
+        lcbar = project_cone_component_lean(cfx, cfy, cfz, vmu, vkc, xm, dir_xy, dir_z);
+        lr = x - lcbar;                   // :96
+        mulc += lr;                       // :102
+      }
+      publish_w(PAR);
+      lds_fence();
+      // exit test :105-109, this wave's part (a lane without a variable has x_res == 0 and passes)
+      const bool wave_fails = (__builtin_amdgcn_ballot_w64(!(fabs(xr) < eps_b)) |
+                               (cone_lanes & __builtin_amdgcn_ballot_w64(!(fabs(lr) < eps_f)))) != 0;
+      publish_flag(PAR, wave_fails);
+      wg_barrier();
+      fetch_w(PAR);
+      lds_fence();
+      return false;
+    };
+    // two iterations per trip: the parity of the exchange copies is a compile-time constant in each (a wave may be a
+    // whole iteration ahead of the slowest reader of the previous copies, never two)
+    {
+      int iter = 0;
+      bool left = false;
+#pragma nounroll
+      while (iter < max_iter) {
+        if (iteration(std::integral_constant<int, 1>{})) { left = true; break; }
+        if (++iter >= max_iter) break;
+        if (iteration(std::integral_constant<int, 0>{})) { left = true; break; }
+        ++iter;
+      }
+      // (`iter` iterations ran; the last one's words are in Wq either way)
+      if (max_iter > 0 && (left || everyone_passed())) n_iter = iter - 1;
+    }
+    ph_p4 = wall_clock64() - t4;
+
+    // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back; the lower lane half of every ADMM wave reports ---------
+    const bool mine = isvar && half == 0;
+    const double ffy = contact_bcast<1, true>(x), ffz = contact_bcast<2, true>(x);
+    double bv = 0.0, cv = 0.0;
+    if (mine) {
+      const double tt = min2(x, vub);
+      const double pj = max2(tt, vlb);
+      const double dd = x - pj;
+      bv = dd * dd;                                        // constraint_utils.cpp:61-65
+    }
+    if (is_cone && ccomp == 0 && half == 0) {
+      const double v = sqrt(x * x + ffy * ffy) - vmu * ffz;
+      cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
+    }
+    bv = wave_sum(bv);
+    cv = wave_sum(cv);
+    double xrn = 0.0, lrn = 0.0;
+    if (max_iter > 0) {
+      xrn = wave_max(isvar ? fabs(xr) : 0.0);              // :97-98
+      lrn = wave_max(is_cone ? fabs(lr) : 0.0);
+    }
+    lds_f64 *const red = L + SH::kRed2;
+    if (mine) {
+      xs[vi] = x;
+      mux_s[vi] = mux;                                     // duals are part of the warm-start state (fcc_qp.hpp:149-150)
+    }
+    if (is_cone && half == 0) mulc_s[vi - s0] = mulc;
+    if (lane == 0) {
+      red[4 * (WV & 3) + 0] = xrn; red[4 * (WV & 3) + 1] = lrn; red[4 * (WV & 3) + 2] = bv; red[4 * (WV & 3) + 3] = cv;
+    }
+    wg_barrier();
+    if (WV == 0 && lane == 0) {
+      double r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+#pragma unroll
+      for (int hh = 1; hh < 4; ++hh) {
+        r0 = max2(r0, red[4 * hh + 0]); r1 = max2(r1, red[4 * hh + 1]);
+        r2 += red[4 * hh + 2]; r3 += red[4 * hh + 3];
+      }
+      a.n_iter[inst] = n_iter;
+      a.flags[inst] = flags;
+      a.metrics[0 * (size_t)a.batch + inst] = r0;
+      a.metrics[1 * (size_t)a.batch + inst] = r1;
+      a.metrics[2 * (size_t)a.batch + inst] = sqrt(r2);
+      a.metrics[3 * (size_t)a.batch + inst] = r3;
+      a.factor_ticks[inst] = ticks;
+      if (a.phase_ticks) {
+        const size_t B = (size_t)a.batch;
+        a.phase_ticks[0 * B + inst] = ph_asm;
+        a.phase_ticks[1 * B + inst] = ticks;
+        a.phase_ticks[2 * B + inst] = ph_solve;
+        a.phase_ticks[3 * B + inst] = ph_p3;
+        a.phase_ticks[4 * B + inst] = ph_p4;
+        a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
+        a.phase_ticks[6 * B + inst] = ph_wfac;        // (of slot 1: the factorisation of W alone)
+        a.phase_ticks[7 * B + inst] = t_begin;
+      }
+    }
+    return;
+  } else {
   constexpr int CSA = SH::CSA;
   lds_f64 *const part = L + SH::kBig + SH::kPart;
   lds_f64 *const wv = L + SH::kBig + SH::kWvOff + ((RH == 1) ? WV : 0) * SH::kWv;
@@ -858,6 +1141,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       a.phase_ticks[7 * B + inst] = t_begin;
     }
   }
+  }   // (n <= 64: column-split layout)
 }
 
 template <class SH, class TIN>

@@ -117,6 +117,11 @@ __device__ __forceinline__ double select_lanes_or_zero(const unsigned long long 
   asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(if_set)), "s"(mask));
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ int select32_lanes(const unsigned long long mask, const int if_set, const int if_clear) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+  return r;
+}
 __device__ __forceinline__ double select64(const bool c, const double if_true, const double if_false) {
   return select_lanes(__builtin_amdgcn_ballot_w64(c), if_true, if_false);
 }
@@ -228,6 +233,25 @@ __device__ __forceinline__ double project_cone_component(double fx, double fy, d
   // backend makes this a branch around the outside-the-cone work or two VOP2 selects on VCC changed from build to build
   const unsigned long long keep = __builtin_amdgcn_ballot_w64(fz != 0.0) & __builtin_amdgcn_ballot_w64(!polar);
   const double outside = select_lanes_or_zero(keep, t * dir);
+  return select64(inside, v, outside);
+}
+
+// The same projection in fewer issue slots, for the one-wave kernel's ADMM loop (every instruction of that loop is
+// 0.27 % of a solve): |f_xy|^2 with one fma; the polar cone by clamping the numerator of t at zero (t = 0: the
+// origin) instead of a compare, a mask operation and part of a select; the z lanes' direction 1 by a per-lane pair
+// of constants (dxy, dz) = (1, 0) on x / y lanes, (0, 1) on z lanes, dir = (rs v) dxy + dz, instead of a select.
+// Same values as project_cone_component for finite input, up to the sign of a zero result and the one rounding
+// the fma saves.
+__device__ __forceinline__ double project_cone_component_lean(double fx, double fy, double fz, double mu, double kc,
+                                                              double v, double dxy, double dz) {
+  const double nxy2 = fma(fy, fy, fx * fx);
+  const double rs = fast_rsqrt(__builtin_fmax(nxy2, DBL_MIN));
+  const double nxy = nxy2 * rs;
+  const bool inside = mu * fz >= nxy;                   // :10-12
+  const double t = __builtin_fmax(fma(mu, nxy, fz), 0.0) * kc;   // :15-17 (polar cone: 0) and :20-23
+  const double dir = fma(rs * v, dxy, dz);
+  // zero ray (f_z == 0): Eigen's normalize() no-op -> 0
+  const double outside = select_lanes_or_zero(__builtin_amdgcn_ballot_w64(fz != 0.0), t * dir);
   return select64(inside, v, outside);
 }
 
@@ -550,7 +574,8 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
         if (NB == 0 && J == cbd && c == n && row < n) vbuf[row] = Gt[I][J][r];     // x_c
         if (J < NW) {
           const double unit = (I == J && row == c) ? 1.0 : 0.0;
-          Wt[I][J][r] = inside ? unit - g4[r] : unit;
+          if (interior) Wt[I][J][r] = unit - g4[r];
+          else Wt[I][J][r] = select_lanes(__builtin_amdgcn_ballot_w64(inside), unit - g4[r], unit);   // (VOP3 select)
         }
       }
       if (interior || c < n) {
@@ -1002,10 +1027,16 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
           M[SW::kZeroFilled ? SW::kDinv + jcol : cb + jcol] = rmine;
           // (entries above the diagonal go to a per-lane dummy slot of the dead exchange tile: one select
           // of the address instead of an exec-mask round trip per store)
+          // (the select written out as VOP3 on a ballot: the compiler's own `v_cmp -> VCC, s_nop 1, v_cndmask_b32_e32`
+          // costs this lone wave 32 cycles per address, 5 + 5 this way; `colv`: hidden from CSE, or the fifteen masks
+          // are hoisted out of the panels and spilled to VGPR lanes)
+          int colv = col;
+          asm volatile("" : "+v"(colv));
+          const int below0 = cb + 16 * P, dummy = kOff + colv;
 #pragma unroll
           for (int i = 1; i < kValid; ++i) {
-            lds_f64 *dst = (i > col) ? M + cb + 16 * P + i : Sblk + col;
-            *dst = T[i] * rmine;
+            const int idx = select32_lanes(__builtin_amdgcn_ballot_w64(i > colv), below0 + i, dummy);
+            M[idx] = T[i] * rmine;
           }
         }
       }
@@ -1260,6 +1291,26 @@ __device__ __forceinline__ void dpp_matvec_pairs(double &acc, const double (&Wq)
   }
 }
 
+// All four blocks in one statement (shapes with 49 <= n <= 63): one `s_waitcnt` for both pairs of w copies in front
+// of it instead of two.
+#define FCCQP_MV_QUAD(L)                                                                                      \
+  asm(FCCQP_MV16(0) FCCQP_MV16(1) FCCQP_MV16(2) FCCQP_MV##L(3)                                                \
+      : [acc] "+v"(acc) : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), FCCQP_MVOPS(0, m0), FCCQP_MVOPS(1, m1), \
+        FCCQP_MVOPS(2, m2), FCCQP_MVOPS(3, m3))
+template <int NN>
+__device__ __forceinline__ void dpp_matvec_quad(double &acc, const double (&Wq)[4], const double (&Mrow)[NN]) {
+  static_assert(NN > 48 && NN <= 64, "four blocks");
+  constexpr int L = NN - 48;
+  double m0[16], m1[16], m2[16], m3[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    m0[i] = Mrow[i]; m1[i] = Mrow[16 + i]; m2[i] = Mrow[32 + i];
+    m3[i] = Mrow[(48 + i < NN) ? 48 + i : NN - 1];
+  }
+  const double w0 = Wq[0], w1 = Wq[1], w2 = Wq[2], w3 = Wq[3];
+  FCCQP_MV_DISPATCH(FCCQP_MV_QUAD);
+}
+
 // forces v[J .. NN) into (arch) VGPRs at this point of the program, ten at a time
 template <int J, int NN>
 __device__ __forceinline__ void pin_vgprs(double (&v)[NN]) {
@@ -1328,7 +1379,8 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
   int var_i = isvar ? 1 : 0, cone_i = is_cone ? 1 : 0, z_i = (ccomp == 2) ? 1 : 0;
   double eps_b = a.eps_bound, eps_f = a.eps_fcone;
   const double vkc = cone_lane_constant(vmu, ccomp == 2);
-  asm volatile("" : "+v"(var_i), "+v"(cone_i), "+v"(z_i), "+v"(eps_b), "+v"(eps_f));
+  double dir_xy = (ccomp == 2) ? 0.0 : 1.0, dir_z = (ccomp == 2) ? 1.0 : 0.0;     // project_cone_component_lean
+  asm volatile("" : "+v"(var_i), "+v"(cone_i), "+v"(z_i), "+v"(eps_b), "+v"(eps_f), "+v"(dir_xy), "+v"(dir_z));
   // w goes to vbuf[variable]; lanes without a variable write entry 63, which is no variable's (n < 64)
   // and is never multiplied (the mat-vec stops at column n-1)
   lds_f64 *const wslot = vbuf + (isvar ? var : kWave - 1);
@@ -1378,13 +1430,19 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
       // reads and the s_waitcnt sits in between; tests/test_code_objects.py fails on a build where the
       // compiler puts a copy there.  An `s_nop 1` pinned here used to cost 16 cycles per iteration.)
       double acc = xc_v;
+      // (all four blocks in ONE asm statement where there are four: a second statement means a second s_waitcnt and an
+      // s_nop between them, and that costs this loop 2 % -- measured; -DFCCQP_MV_TWO_STATEMENTS builds the pairs)
+#ifndef FCCQP_MV_TWO_STATEMENTS
+      if constexpr (NQ == 4) dpp_matvec_quad<n>(acc, Wq, Mrow);
+      else dpp_matvec_pairs<0, n, NQ>(acc, Wq, Mrow);
+#else
       dpp_matvec_pairs<0, n, NQ>(acc, Wq, Mrow);
+#endif
       x = acc;
       // slack update :90-92.  The contact force (x + mu_lambda_c)[3c .. 3c+2] sits in the first three lanes of this
       // lane's 16-lane row (or quad, Shape::kRowContacts): three DPP broadcasts, no LDS round trip
-      const double xm = x + mulc;       // lanes outside the contacts: mulc == 0, value unused
+      double xm = x + mulc;             // lanes outside the contacts: mulc == 0, value unused
       constexpr bool kRow = SH::kRowContacts;
-      const double cfx = contact_bcast<0, kRow>(xm), cfy = contact_bcast<1, kRow>(xm), cfz = contact_bcast<2, kRow>(xm);
       // Every lane runs both updates, unmasked (a select per state variable per iteration otherwise).  A
       // lane without a variable has x = mu_x = 0 and infinite bounds: it stays at zero.  Outside the
       // contacts lcbar / lr / mulc are garbage that nothing reads: w, the exit test, the reported norms
@@ -1400,7 +1458,8 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
         mux += xr;                        // :101
       }
       {
-        lcbar = project_cone_component(cfx, cfy, cfz, vmu, vkc, xm, z_lanes);
+        const double cfx = contact_bcast<0, kRow>(xm), cfy = contact_bcast<1, kRow>(xm), cfz = contact_bcast<2, kRow>(xm);
+        lcbar = project_cone_component_lean(cfx, cfy, cfz, vmu, vkc, xm, dir_xy, dir_z);
         lr = x - lcbar;                   // :96
         mulc += lr;                       // :102
       }
@@ -1410,13 +1469,18 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
       // a boolean out of them) instead of two wave reductions; the norms themselves (:97-98) are only reported,
       // and are reduced once after the loop.  An empty contact set has norm 0.  n_iter: the index of the
       // iteration that passed the test, or max_iter.
-      const unsigned long long fail = (var_lanes & __builtin_amdgcn_ballot_w64(!(fabs(xr) < eps_b))) |
-                                      (cone_lanes & __builtin_amdgcn_ballot_w64(!(fabs(lr) < eps_f)));
+      // (no lane mask on the first compare: a lane without a variable has x_res == 0 exactly, which passes whenever a
+      // real lane can pass at all -- with eps_bound <= 0 or NaN every lane fails, variable or not, and the loop runs
+      // to max_iter either way)
+      const unsigned long long fail_b = __builtin_amdgcn_ballot_w64(!(fabs(xr) < eps_b)),
+                               fail_f = __builtin_amdgcn_ballot_w64(!(fabs(lr) < eps_f));
       // one exit: a converged iteration is not counted and drops the bound to zero.  Written out, because the
       // backend turns every formulation of "break, or count and compare" into the same twelve SALU instructions
-      // (each one an issue slot of this lone wave like any other instruction); these are three plus the compare
-      asm volatile("s_cmp_lg_u64 %2, 0\n\ts_cselect_b32 %1, %3, 0\n\ts_addc_u32 %0, %0, 0"
-                   : "+s"(iter), "=&s"(bound) : "s"(fail), "s"(max_iter) : "scc");
+      // (each one an issue slot of this lone wave like any other instruction): s_and / s_or of the masks -- the s_or
+      // leaves SCC = "some lane fails" --, then bound = SCC ? max_iter : 0 and iter += SCC
+      unsigned long long fail;
+      asm volatile("s_and_b64 %2, %4, %5\n\ts_or_b64 %2, %2, %3\n\ts_cselect_b32 %1, %6, 0\n\ts_addc_u32 %0, %0, 0"
+                   : "+s"(iter), "=&s"(bound), "=&s"(fail) : "s"(fail_b), "s"(fail_f), "s"(cone_lanes), "s"(max_iter) : "scc");
     } while (iter < bound);
     n_iter = iter;
   }

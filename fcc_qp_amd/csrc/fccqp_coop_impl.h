@@ -147,8 +147,10 @@ struct Shape {
   // diagonal tile exchange: the tile on its way to the column-per-lane layout (owner only), then L^-1 and 1/d in
   // TWO slots by panel parity: the owner of column p + 1 factorises its diagonal tile while the others are still in
   // the trailing update of panel p (look-ahead), whose L^-1 / 1/d must stay readable until every wave has passed on
-  static constexpr int kSblk = 0, kSinv = 256, kSrcp = 768;            // Sinv[2][256], Srcp[2][16]
-  static constexpr int kRcp = 800;                                      // 1/d of every row of K_rho (16 NRB)
+  // (tile columns 18 doubles apart, as in the one-wave kernel: a 128-byte stride puts a row of the tile on one LDS bank)
+  static constexpr int kTS = 18, kTL = 16 * kTS;
+  static constexpr int kSblk = 0, kSinv = kTL, kSrcp = 3 * kTL;        // Sinv[2][kTL], Srcp[2][16]
+  static constexpr int kRcp = 3 * kTL + 32;                             // 1/d of every row of K_rho (16 NRB)
   static constexpr int kRhs = kRcp + 16 * NRB;                          // [-b; b_eq]; later x_c, x0
   static constexpr int kRhsLen = cmax(16 * NRB, kPos + 64);
   static constexpr int kRed = kRhs + kRhsLen;                           // end-of-solve reductions [RH][4]
@@ -243,16 +245,17 @@ template <int kValid, bool WITH_INVERSE, bool KEEP_L>
 __device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &Cpp, double (&T)[16], double &rmine, const double max_rcp,
                                           const int slot) {
   const int col = lane & 15, grp = lane >> 4;
-  lds_f64 *const Sblk = L + 0, *const Sinv = L + 256 + 256 * slot, *const Srcp = L + 768 + 16 * slot;
+  constexpr int TS = 18, TL = 16 * TS;      // (Shape::kTS, kTL)
+  lds_f64 *const Sblk = L + 0, *const Sinv = L + TL + TL * slot, *const Srcp = L + 3 * TL + 16 * slot;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) Sblk[16 * col + grp + 4 * r] = Cpp[r];
+  for (int r = 0; r < 4; ++r) Sblk[TS * col + grp + 4 * r] = Cpp[r];
   lds_fence();
   double Y[16];
-  const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
+  const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + TS * col);
   const bool bad = tile_ldl<kValid, WITH_INVERSE, KEEP_L>(T, Y, rmine, col, colp, max_rcp);
   if (lane < 16) {
     if constexpr (WITH_INVERSE) {
-      lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
+      lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + TS * col);
 #pragma unroll
       for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
     }
@@ -300,7 +303,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     double Ainv[4], nrv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double li = Sinv[256 * (P & 1) + 16 * (4 * r + grp) + col];
+      const double li = Sinv[SH::kTL * (P & 1) + SH::kTS * (4 * r + grp) + col];
       Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
       nrv[r] = -Srcp[16 * (P & 1) + grp + 4 * r];
     }
@@ -513,7 +516,7 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
       double Ainv[4], rv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double li = Sinv[256 * (P & 1) + 16 * (4 * r + grp) + col];
+        const double li = Sinv[SH::kTL * (P & 1) + SH::kTS * (4 * r + grp) + col];
         Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
         rv[r] = Srcp[16 * (P & 1) + grp + 4 * r];
       }

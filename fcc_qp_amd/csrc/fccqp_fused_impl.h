@@ -288,7 +288,11 @@ struct Packed {
   static constexpr bool kZeroFilled = false;
   // exchange scratch of the diagonal tiles (tile_factor_forward, tile_factor_store): the tile, its inverse,
   // 16 reciprocal pivots (+ padding)
-  static constexpr int kScratch = 544;
+  // (columns 18 doubles apart, not 16: with a stride of 128 bytes the sixteen lanes that store or load one row of
+  // the tile hit one LDS bank -- 16-way conflicts on every store, 8-way on every 16-byte load, 500 LDS cycles per
+  // tile instead of 50; 144 bytes keeps the 16-byte alignment of the loads)
+  static constexpr int kTileStride = 18, kTileLen = 16 * kTileStride;
+  static constexpr int kScratch = 2 * kTileLen + 32;
   static constexpr int kRowsPadded = 16 * ((N + 15) / 16);
   static constexpr int kNp = (N + 1) & ~1;
 };
@@ -323,7 +327,10 @@ struct Shape : Packed<N_VARS + N_EQ> {
   static_assert(nc > 0, "fused shapes have contacts");
   // where tile_factor_forward leaves 1/d_row for gram_output: behind the exchange scratch and behind the rho G
   // image (n x n, row-major) that gram_output writes
-  static constexpr int kRcpOffset = (n * n > KKT::kScratch) ? n * n : KKT::kScratch;
+  // (row stride of that image: even -- the rows are read back 16 bytes at a time -- and 2 mod 4, so that the mirror
+  // stores of a tile, which walk down a column, spread over eight LDS banks instead of four or fewer)
+  static constexpr int kImgStride = ((n + 1) & ~1) + ((((n + 1) & ~1) % 4 == 2) ? 0 : 2);
+  static constexpr int kRcpOffset = (n * kImgStride > KKT::kScratch) ? n * kImgStride : KKT::kScratch;
   // Bordering.  16 x 16 tiles waste most of a last row block that holds only N % 16 rows (walking shape:
   // 2 of 16, and a fifth of all MFMAs touch it).  When those last rows lie in the zero block and the
   // right-hand-side tile column that carries [-b; b_eq] has free columns for them, the tiles factorise
@@ -584,8 +591,8 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
           const int row = 16 * I + grp + 4 * r;
           const bool rows_in = interior || (16 * I + 4 * r + 3 < n), rows_out = !interior && (16 * I + 4 * r >= n);
           if (rows_in || (!rows_out && row < n)) {
-            M[row * n + c] = g4[r];
-            if (J != I) M[c * n + row] = g4[r];                      // the mirror tile
+            M[row * SH::kImgStride + c] = g4[r];
+            if (J != I) M[c * SH::kImgStride + row] = g4[r];         // the mirror tile
           }
         }
       }
@@ -606,7 +613,7 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
   static_assert(SH::KKT::kRowsPadded >= n, "room for a zero row behind the image");
   if (lane < n) M[SH::kRcpOffset + lane] = 0.0;
   lds_fence();
-  const lds_f64 *const rowp = isvar ? M + lr * n : M + SH::kRcpOffset;
+  const lds_f64 *const rowp = isvar ? M + lr * SH::kImgStride : M + SH::kRcpOffset;
   if constexpr (n % 2 == 0 && SH::kRcpOffset % 2 == 0) {
     const lds_d2 *g2 = reinterpret_cast<const lds_d2 *>(rowp);
 #pragma unroll
@@ -891,24 +898,25 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
     }
     return t;
   };
-  lds_f64 *const Sblk = M;          // exchange scratch: diagonal tile, column-major 16 x 16
-  lds_f64 *const Sinv = M + 256;    // its L^-1, column-major
-  lds_f64 *const Srcp = M + 512;    // 1 / d of the tile's rows
+  constexpr int TS = SH::kTileStride;
+  lds_f64 *const Sblk = M;                        // exchange scratch: diagonal tile, column-major 16 x 16 (column stride TS)
+  lds_f64 *const Sinv = M + SH::kTileLen;         // its L^-1, column-major
+  lds_f64 *const Srcp = M + 2 * SH::kTileLen;     // 1 / d of the tile's rows
   bool bad = false;
   static_for<0, NRB>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
     constexpr int kValid = (N - 16 * P < 16) ? N - 16 * P : 16;
     // (1) diagonal tile
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Sblk[16 * col + grp + 4 * r] = C[P][P][r];
+    for (int r = 0; r < 4; ++r) Sblk[TS * col + grp + 4 * r] = C[P][P][r];
     lds_fence();
     double Ainv[4], nrv[4];
     {
       double T[16], Y[16], rmine;
-      const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
+      const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + TS * col);
       FCCQP_FINE(0, bad |= tile_ldl<kValid>(T, Y, rmine, col, colp));
       if (lane < 16) {
-        lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
+        lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + TS * col);
 #pragma unroll
         for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
         Srcp[col] = rmine;
@@ -919,7 +927,7 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       // A[i][k] = (L^-1)[i][4r + k], strictly below the diagonal (the unit diagonal is the accumulator's start)
-      const double li = Sinv[16 * (4 * r + grp) + col];
+      const double li = Sinv[TS * (4 * r + grp) + col];
       Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
       nrv[r] = -Srcp[grp + 4 * r];
     }
@@ -941,7 +949,7 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
           // panels above it only had zero tiles in this column block): L^-1 I is the tile tile_ldl has just
           // left in the exchange area -- four LDS reads instead of four MFMAs
 #pragma unroll
-          for (int r = 0; r < 4; ++r) X[P][cb][r] = Sinv[16 * col + grp + 4 * r];
+          for (int r = 0; r < 4; ++r) X[P][cb][r] = Sinv[TS * col + grp + 4 * r];
         } else {
           if (P == kfirst(cb)) X[P][cb] = x_initial(P, cb);
           d4 t = X[P][cb];
@@ -988,9 +996,10 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
   constexpr int kOff = (SW::kPacked + 1) & ~1;
   static_assert(kOff + SH::kScratch <= SH::kMat, "exchange scratch behind the packed W");
   const int col = lane & 15, grp = lane >> 4;
+  constexpr int TS = SH::kTileStride;
   lds_f64 *const Sblk = M + kOff;
-  lds_f64 *const Sinv = Sblk + 256;
-  lds_f64 *const Srcp = Sblk + 512;
+  lds_f64 *const Sinv = Sblk + SH::kTileLen;
+  lds_f64 *const Srcp = Sblk + 2 * SH::kTileLen;
   if constexpr (SW::kZeroFilled) {
     // zeros on and above the diagonal of the square: the whole of it first (the rho G image it lies over is in
     // registers by now), L then goes on top
@@ -1006,17 +1015,17 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
     constexpr int P = decltype(pc)::value;
     constexpr int kValid = (n - 16 * P < 16) ? n - 16 * P : 16;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Sblk[16 * col + grp + 4 * r] = C[P][P][r];
+    for (int r = 0; r < 4; ++r) Sblk[TS * col + grp + 4 * r] = C[P][P][r];
     lds_fence();
     double Ainv[4], rv[4];
     {
       double T[16], Y[16], rmine;
-      const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + 16 * col);
+      const lds_d2 *colp = reinterpret_cast<const lds_d2 *>(Sblk + TS * col);
       constexpr bool kLast = (P + 1 == NW);
       FCCQP_FINE(0, (bad |= tile_ldl<kValid, !kLast, true>(T, Y, rmine, col, colp, 1.0 / min_pivot)));
       if (lane < 16) {
         if constexpr (!kLast) {
-          lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + 16 * col);
+          lds_d2 *outp = reinterpret_cast<lds_d2 *>(Sinv + TS * col);
 #pragma unroll
           for (int ip = 0; ip < 8; ++ip) outp[ip] = d2{Y[2 * ip], Y[2 * ip + 1]};
           Srcp[col] = rmine;
@@ -1044,7 +1053,7 @@ __device__ __forceinline__ bool tile_factor_store(lds_f64 *M, const int lane, co
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double li = Sinv[16 * (4 * r + grp) + col];
+      const double li = Sinv[TS * (4 * r + grp) + col];
       Ainv[r] = (col > 4 * r + grp) ? li : 0.0;
       rv[r] = Srcp[grp + 4 * r];
     }
@@ -1549,6 +1558,16 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   const int lane = threadIdx.x;
   const int inst = block_instance(a);     // block -> instance map (fccqp_device.h)
   if (inst < 0) return;
+  // Staggered start.  A launch of several wave-rounds keeps the 1024 resident waves in lock step from the first load to
+  // the last store: the four waves of a CU reach every LDS-heavy piece (tile exchanges, the rho G image) and every
+  // burst of global loads together, round after round.  Same-box A/B at batch 4096: starting the waves of SIMD k
+  // k x 1.9 us late takes 2.7 % off the launch (W-sat; the phases then interleave, and the price is at most 5.6 us at
+  // the end); 0.9 us steps gain 2.2 %, 3.7 us steps 2.7 %, 5.6 us steps 1.4 %.  Only the first round waits, and only
+  // in launches of at least two rounds: a one-round launch would just end later.  (HW_REG_HW_ID bits 5:4: the SIMD.)
+  if (gridDim.x >= 2048u && blockIdx.x < 1024u) {
+    const int simd = (int)((__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11))) & 3);
+    for (int k = 0; k < 4 * simd; ++k) __builtin_amdgcn_s_sleep(16);       // 16 x 64 cycles ~ 0.47 us
+  }
 
   const TIN *__restrict__ Q = reinterpret_cast<const TIN *>(a.Q) + (size_t)inst * n * n;
   const TIN *__restrict__ A = reinterpret_cast<const TIN *>(a.A) + (size_t)inst * m * n;

@@ -1359,26 +1359,41 @@ struct AdmmLane {
 // `fresh()` hides a pointer from CSE so that a load is redone at the point of use instead of its value being
 // kept in a register (or in scratch) across the factorisation
 __device__ __forceinline__ const double *fresh(const double *p) { asm volatile("" : "+s"(p)); return p; }
+// The ADMM lane's own small inputs -- bounds, friction coefficient and, on a warm start, its duals -- ISSUED EARLY: right
+// after the Gram product, a presolve ahead of their first use.  (Through round 3 they were loaded where the loop begins
+// and again in the epilogue, and the wave sat through a memory round trip each time -- 1-2 us with the chip under
+// load; before the Gram product there is no register to spare for them, after it there is.)  Unconditional loads
+// from clamped indices: no branch; the lane kind is applied where the values are used.
+struct LaneInputs { double lb, ub, mu, mux, mulc; };
+template <class SH>
+__device__ __forceinline__ LaneInputs load_lane_inputs(const KernelArgs &a, const AdmmLane<SH> &L) {
+  LaneInputs v;
+  v.lb = fresh(L.lbp)[L.vi];
+  v.ub = fresh(L.ubp)[L.vi];
+  v.mu = fresh(L.mup)[L.cidx];
+  v.mux = 0.0;
+  v.mulc = 0.0;
+  if (a.warm_start) {  // fcc_qp.cpp:136-139
+    v.mux = L.mux_s[L.vi];
+    v.mulc = L.mulc_s[L.is_cone ? L.vi - SH::s : 0];
+  }
+  return v;
+}
 
 // P4: ADMM iterations (fcc_qp.cpp:74-110) from x (the presolve's x0, or the warm-start state) with this lane's
 // row Mrow of rho G and entry xc of x_c; leaves the last iterate in x, the duals in the warm-start state.
 template <class SH>
 __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmLane<SH> &L, const int lane, lds_f64 *vbuf,
                                                 double (&Mrow)[SH::n], const double xc, double &x, int &n_iter,
-                                                double &x_res_norm, double &lc_res_norm) {
+                                                double &x_res_norm, double &lc_res_norm, const LaneInputs &in) {
   constexpr int n = SH::n, s0 = SH::s;
   const bool isvar = L.isvar, is_cone = L.is_cone;
   const int var = L.var, vi = L.vi, cidx = L.cidx, ccomp = L.ccomp;
-  const double *lbp = L.lbp, *ubp = L.ubp, *mup = L.mup;
   double *mux_s = L.mux_s, *mulc_s = L.mulc_s;
-  const double vlb = isvar ? fresh(lbp)[vi] : -HUGE_VAL;
-  const double vub = isvar ? fresh(ubp)[vi] : HUGE_VAL;
-  const double vmu = is_cone ? fresh(mup)[cidx] : 0.0;
-  double mux = 0.0, mulc = 0.0;
-  if (a.warm_start) {  // fcc_qp.cpp:136-139
-    mux = isvar ? mux_s[vi] : 0.0;
-    mulc = is_cone ? mulc_s[is_cone ? vi - s0 : 0] : 0.0;
-  }
+  const double vlb = isvar ? in.lb : -HUGE_VAL;
+  const double vub = isvar ? in.ub : HUGE_VAL;
+  const double vmu = is_cone ? in.mu : 0.0;
+  double mux = isvar ? in.mux : 0.0, mulc = is_cone ? in.mulc : 0.0;    // (zero on a cold start, fcc_qp.cpp:136-139)
   double xbar = x, lcbar = x;  // :74-75
   double xr = 0.0, lr = 0.0;
   // The loop's wave-uniform operands (lane masks, the two eps) are re-made here as per-lane
@@ -1472,7 +1487,12 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
         lr = x - lcbar;                   // :96
         mulc += lr;                       // :102
       }
+#ifdef FCCQP_PROBE_NO_EXCHANGE
+      // timing probe (WRONG results): the loop without its LDS exchange -- what a free exchange would buy
+      { double w = select_lanes(cone_lanes, lcbar - mulc, xbar - mux); asm volatile("" :: "v"(w)); }
+#else
       exchange_w();                       // for the next iteration (harmless after the last)
+#endif
       // exit test :105-109.  norm_inf(r) < eps  <=>  every |r_i| < eps, so the per-iteration test is two compares
       // whose lane masks meet in scalar registers (s_and / s_or set SCC for the branch: no VALU instruction makes
       // a boolean out of them) instead of two wave reductions; the norms themselves (:97-98) are only reported,
@@ -1507,23 +1527,22 @@ __device__ __forceinline__ void admm_iterations(const KernelArgs &a, const AdmmL
 template <class SH>
 __device__ __forceinline__ void epilogue_writeback(const KernelArgs &a, const AdmmLane<SH> &L, const int inst, const int lane,
                                                    const double x, const int n_iter, const int flags,
-                                                   const double x_res_norm, const double lc_res_norm) {
+                                                   const double x_res_norm, const double lc_res_norm, const LaneInputs &in) {
   const bool isvar = L.isvar, is_cone = L.is_cone;
   const int vi = L.vi, cidx = L.cidx, ccomp = L.ccomp;
-  const double *lbp = L.lbp, *ubp = L.ubp, *mup = L.mup;
   double *xs = L.xs;
   lds_fence();
   const double ffy = contact_bcast<1, SH::kRowContacts>(x), ffz = contact_bcast<2, SH::kRowContacts>(x);   // this lane's contact force
   double bv = 0.0, cv = 0.0;
   if (isvar) {
-    const double tt = min2(x, fresh(ubp)[vi]);
-    const double p = max2(tt, fresh(lbp)[vi]);
+    const double tt = min2(x, in.ub);
+    const double p = max2(tt, in.lb);
     const double dd = x - p;
     bv = dd * dd;                                        // constraint_utils.cpp:61-65
   }
   if (is_cone && ccomp == 0) {
     const double fx = x, fy = ffy, fz = ffz;
-    const double v = sqrt(fx * fx + fy * fy) - fresh(mup)[cidx] * fz;
+    const double v = sqrt(fx * fx + fy * fy) - in.mu * fz;
     cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
   }
   bv = sqrt(wave_sum(bv));
@@ -1624,6 +1643,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
 
   int n_iter = 0;
   double x_res_norm = 0.0, lc_res_norm = 0.0;
+  LaneInputs in{};
   // phase stamps (100 MHz): 0 load issue, 1 factorisations, 2 presolve (W), 3 Gram product, 4 ADMM loop, 5 total
   long long ph_asm = 0, ph_solve = 0, ph_p3 = 0, ph_p4 = 0;
   const long long t_begin = wall_clock64();
@@ -1669,6 +1689,8 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       t4 = wall_clock64();
       ph_p3 = t4 - t3;
     }
+    // the ADMM lane's bounds / friction coefficient / warm duals: on their way from here (load_lane_inputs)
+    if constexpr (!SPLIT) in = load_lane_inputs<SH>(a, AdmmLane<SH>(a, inst, lane));
 
     // ---- presolve (fcc_qp.cpp:159-178; skipped on warm start) ----------------------------------------
     // x0 = (K^-1 r).head(n), r = [-b; b_eq].  With E = [I_n; 0], K = K_rho - rho E E^T, and the
@@ -1749,13 +1771,13 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     }
     // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------
     const AdmmLane<SH> L(a, inst, lane);
-    admm_iterations<SH>(a, L, lane, vbuf, Mrow, xc, x, n_iter, x_res_norm, lc_res_norm);
+    admm_iterations<SH>(a, L, lane, vbuf, Mrow, xc, x, n_iter, x_res_norm, lc_res_norm, in);
     ph_p4 = wall_clock64() - t4;
   }
 
   // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back -----------------------------------------
   const AdmmLane<SH> L(a, inst, lane);
-  epilogue_writeback<SH>(a, L, inst, lane, x, n_iter, flags, x_res_norm, lc_res_norm);
+  epilogue_writeback<SH>(a, L, inst, lane, x, n_iter, flags, x_res_norm, lc_res_norm, in);
   if (lane == 0) {
     a.factor_ticks[inst] = ticks;
     if (a.phase_ticks) {
@@ -1807,8 +1829,9 @@ __global__ __launch_bounds__(kWave, WAVES_PER_SIMD) void admm_kernel(const Kerne
   double x = L.isvar ? L.xs[L.vi] : 0.0;
   int n_iter = 0;
   double x_res_norm = 0.0, lc_res_norm = 0.0;
-  admm_iterations<SH>(a, L, lane, vbuf, Mrow, xc, x, n_iter, x_res_norm, lc_res_norm);
-  epilogue_writeback<SH>(a, L, inst, lane, x, n_iter, flags, x_res_norm, lc_res_norm);
+  const LaneInputs in = load_lane_inputs<SH>(a, L);
+  admm_iterations<SH>(a, L, lane, vbuf, Mrow, xc, x, n_iter, x_res_norm, lc_res_norm, in);
+  epilogue_writeback<SH>(a, L, inst, lane, x, n_iter, flags, x_res_norm, lc_res_norm, in);
   if (lane == 0 && a.phase_ticks) {
     const size_t B = (size_t)a.batch;
     const long long dt = wall_clock64() - t_begin;

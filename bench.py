@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--workload", default="W-sat", choices=["W-sat", "W-mix", "W-easy", "W-psd"])
     ap.add_argument("--shape", default="walking", choices=["walking", "large"],
                     help="walking = FCCQP(60,38,12,38), the metric's shape; large = FCCQP(114,60,24,66), "
-                         "BASELINE configs[3] (secondary: cooperative kernel, four waves per QP)")
+                         "BASELINE configs[3] (secondary: cooperative kernel, eight waves per QP)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fused", "fused_split", "coop"])
     ap.add_argument("--options", default="harness", choices=["harness", "paper"],
                     help="harness: fcc_qp_test.py:78-83 (headline); paper: fccqp.pdf Table 1 (max_iter=15, eps=1e-4)")
@@ -285,7 +285,7 @@ def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup
     # the two-launch form of the fused kernel (ADMM loop at two waves per SIMD): the measured A/B of DESIGN.md section 7
     run("fused_split", P.WALKING, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_FUSED_SPLIT)
     run("fused_split_w_mix", P.WALKING, "W-mix", P.HARNESS_OPTIONS, kernel=F.KERNEL_FUSED_SPLIT)
-    # BASELINE configs[3]: 36-DoF / 8-contact shape -- cooperative kernel (four waves per QP share the register
+    # BASELINE configs[3]: 36-DoF / 8-contact shape -- cooperative kernel (eight waves per QP share the register
     # tiles), and the generic kernel it replaced for this shape
     run("large_shape", P.LARGE, "W-sat", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
     run("large_shape_generic", P.LARGE, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_GENERIC, distinct=32, parity_k=16, steps=4, warmup=1)

@@ -105,5 +105,34 @@ def build_all(force: bool = False) -> None:
     build_pymod(force)
 
 
+def add_shape(kind: str, dims) -> bool:
+    """Appends a shape to csrc/fused_shapes.def (kind "fused": num_vars <= 63, one wavefront per QP) or
+    csrc/coop_shapes.def (kind "coop": num_vars <= 128, `waves` wavefronts per QP) unless it is listed already;
+    the next build compiles the specialised kernel for it (static_asserts in the kernels' Shape structs say so if the
+    shape does not qualify).  Every other shape runs on the generic kernel, several times slower."""
+    dims = tuple(int(d) for d in dims)
+    if kind == "fused":
+        assert len(dims) == 4, "fused shape: num_vars num_equality_constraints nc lambda_c_start"
+        path, line = os.path.join(CSRC, "fused_shapes.def"), "FCCQP_FUSED_SHAPE(%d, %d, %d, %d)" % dims
+    else:
+        assert len(dims) == 5, "coop shape: num_vars num_equality_constraints nc lambda_c_start waves"
+        path, line = os.path.join(CSRC, "coop_shapes.def"), "FCCQP_COOP_SHAPE(%d, %d, %d, %d, %d)" % dims
+    text = open(path).read()
+    listed = {l.split("//")[0].replace(" ", "") for l in text.splitlines()}
+    if line.replace(" ", "") in listed:
+        return False
+    with open(path, "a") as f:
+        f.write(("" if text.endswith("\n") else "\n") + line + "   // added by fcc_qp_amd/build.py --add-%s-shape\n" % kind)
+    return True
+
+
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    # python fcc_qp_amd/build.py [--force] [--add-fused-shape n m nc s] [--add-coop-shape n m nc s waves]
+    argv = sys.argv[1:]
+    for flag, kind, k in (("--add-fused-shape", "fused", 4), ("--add-coop-shape", "coop", 5)):
+        while flag in argv:
+            i = argv.index(flag)
+            added = add_shape(kind, argv[i + 1:i + 1 + k])
+            print("[build] %s shape %s: %s" % (kind, " ".join(argv[i + 1:i + 1 + k]), "added" if added else "already listed"))
+            del argv[i:i + 1 + k]
+    build_all(force="--force" in argv)

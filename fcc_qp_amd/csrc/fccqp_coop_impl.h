@@ -993,6 +993,8 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     }
     return;
   } else {
+  // ---- n <= 64: the columns of rho G split over CSA waves, partial sums through LDS ------------------------------
+  static_assert(RH == 1, "column-split layout: one row half (n > 64 takes the row-split layout above)");
   constexpr int CSA = SH::CSA;
   lds_f64 *const part = L + SH::kBig + SH::kPart;
   lds_f64 *const wv = L + SH::kBig + SH::kWvOff + ((RH == 1) ? WV : 0) * SH::kWv;

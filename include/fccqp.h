@@ -82,7 +82,7 @@ enum {
                                 W = I - rho G, mat-vec ADMM iterations with DPP-fed FMAs               */
   FCCQP_KERNEL_FUSED_SPLIT = 3, /* the same in two launches: everything up to the presolve at one wave
                                 per SIMD, then the ADMM iterations + epilogue at two waves per SIMD
-                                (rho G takes a round trip through a device workspace of 8 * 64 * 65
+                                (rho G takes a round trip through a device workspace of 8 * 64 * (n + 1)
                                 bytes per instance).  Bit-identical results; measured 3-4 % faster (round 3; 7 % slower since round 4) at
                                 batch 4096 with 100 iterations, 8 % slower with the paper's 15: AUTO
                                 never picks it                                  */

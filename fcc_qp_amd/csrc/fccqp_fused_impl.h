@@ -402,7 +402,7 @@ template <class SH>
 __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho, const int grow,
                                             const d4 (&X)[(SH::N1 + 15) / 16][kWave / 16],
                                             d4 (&Wt)[(SH::n + 15) / 16][(SH::n + 15) / 16], double (&Mrow)[SH::n],
-                                            double &xc, long long *fine = nullptr) {
+                                            double &xc, double &gdiag, long long *fine = nullptr) {
   constexpr int N = SH::N1, n = SH::n, NRB = (N + 15) / 16, NW = (n + 15) / 16, NB = SH::kBorder;
   const int col = lane & 15, grp = lane >> 4;
 #ifdef FCCQP_FINE_STAMPS
@@ -608,6 +608,7 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
   const bool isvar = grow >= 0;
   const int lr = isvar ? grow : 0;
   xc = isvar ? vbuf[lr] : 0.0;
+  gdiag = isvar ? M[lr * SH::kImgStride + lr] : 0.0;       // (rho G)[var][var]: the diagonal of W = I - rho G, for the presolve
   // (a lane without a variable reads a row of zeros laid over the reciprocal pivots, which are in registers by now:
   // one select of the row address instead of two per entry of the row)
   static_assert(SH::KKT::kRowsPadded >= n, "room for a zero row behind the image");
@@ -1380,6 +1381,64 @@ __device__ __forceinline__ LaneInputs load_lane_inputs(const KernelArgs &a, cons
   return v;
 }
 
+// ---- presolve by conjugate gradients (round 4) ------------------------------------------------------------------
+// x0 = W^-1 x_c with W = I - rho G (the Woodbury form of the reference's presolve, fcc_qp.cpp:159-178; see the kernel
+// body).  W is symmetric positive definite exactly when K is non-singular, its eigenvalues are 1 on range(A_eq^T) and
+// lambda / (lambda + rho) for the eigenvalues lambda of the reduced Hessian -- at most n - m + 1 DISTINCT eigenvalues, so
+// conjugate gradients end in at most n - m + 1 steps in exact arithmetic whatever the condition number, and the rows
+// of rho G are in registers already (Mrow, the ADMM layout): an iteration is the ADMM loop's mat-vec, two wave
+// reductions and three FMAs, ~0.3 us.  Emulated in fp64 on the CPU (tools/cg_presolve_experiment.py) and measured on
+// the device: 11-13 iterations to a relative residual of 1e-13 on W-sat / W-psd (cond(W) 24 .. 450), 4-12 on W-mix,
+// x0 within 7e-14 of the direct solve -- 3.5 us against the 11.9 us of factorising W by tiles and sweeping twice.
+// Returns false -- and the caller takes that direct path, with its own singularity rule and the COD hand-off -- when
+//   * the diagonal of W has an entry <= kPresolveMinPivot (every pivot of W's LDL^T is <= its diagonal entry: the direct
+//     path would declare K singular; a variable without cost or constraint -- the tested case -- shows exactly so),
+//   * a search direction has p.Wp <= 1e-10 r.r (a Rayleigh quotient that small means an eigenvalue that small), or
+//   * the residual has not reached 1e-13 |x_c| after kCap iterations (ill-conditioned W).
+// On success x is x0 in the ADMM layout (this lane's variable).  vbuf is used for the exchange of p.
+constexpr double kCgTolSquared = 1e-26;
+template <class SH>
+__device__ __forceinline__ bool cg_presolve(lds_f64 *vbuf, const int lane, const bool isvar, const int var,
+                                            const double (&Mrow)[SH::n], const double xc, const double gdiag, double &x) {
+  constexpr int n = SH::n, NQ = (n + 15) / 16;
+  constexpr int kCap = (n - SH::m > 0 ? n - SH::m : n) + 10;
+  if (__builtin_amdgcn_ballot_w64(isvar && !(1.0 - gdiag > kPresolveMinPivot)) != 0) return false;
+  lds_f64 *const pslot = vbuf + (isvar ? var : kWave - 1);
+  double r = xc, p = xc, xs = 0.0;                           // x = 0: r = b = x_c (zero in a lane without a variable)
+  double rs = wave_sum(r * r);
+  const double bb = rs;
+  if (!(bb > 0.0)) { x = 0.0; return bb == 0.0; }            // x_c == 0: x0 = 0 (NaN: leave it to the direct path)
+  const double stop = kCgTolSquared * bb;
+  bool done = false;
+#pragma nounroll
+  for (int it = 0; it < kCap; ++it) {
+    // Wp = p - (rho G) p: the ADMM loop's mat-vec on p
+    *pslot = p;
+    lds_fence();
+    double Wq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) Wq[q] = vbuf[16 * q + (lane & 15)];
+    lds_fence();
+    double acc = 0.0;
+    if constexpr (NQ == 4) dpp_matvec_quad<n>(acc, Wq, Mrow);
+    else dpp_matvec_pairs<0, n, NQ>(acc, Wq, Mrow);
+    const double wp = p - acc;
+    const double pwp = wave_sum(p * wp);
+    if (!(pwp > 1e-10 * rs)) break;                          // (also NaN)
+    const double alpha = rs * fast_rcp(pwp);
+    xs = fma(alpha, p, xs);
+    r = fma(-alpha, wp, r);
+    const double rs_new = wave_sum(r * r);
+    if (rs_new <= stop) { done = true; break; }
+    const double beta = rs_new * fast_rcp(rs);
+    p = fma(beta, p, r);
+    rs = rs_new;
+  }
+  lds_fence();
+  x = xs;
+  return done;
+}
+
 // P4: ADMM iterations (fcc_qp.cpp:74-110) from x (the presolve's x0, or the warm-start state) with this lane's
 // row Mrow of rho G and entry xc of x_c; leaves the last iterate in x, the duals in the warm-start state.
 template <class SH>
@@ -1662,7 +1721,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     // ---- P1 + P3: factorisation of K_rho with the forward solve of [E | -b; b_eq] fused in, then
     // rho G = rho (K_rho^-1)[0:n,0:n] and x_c = (K_rho^-1 [-b; b_eq])[0:n] as a Gram product ----------
     double Mrow[n];
-    double xc;
+    double xc, gdiag;
     long long t4;
     constexpr int NW = (n + 15) / 16;
     d4 Wt[NW][NW];   // upper tiles of W = I - rho G, from the Gram product to the presolve
@@ -1685,7 +1744,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       if (tile_factor_forward<SH>(M, vbuf, lane, C, X, fine_k)) flags |= kFlagAdmmNumerical;
       const long long t3 = wall_clock64();
       ticks = t3 - t0;
-      if (gram_output<SH>(M, vbuf, lane, a.rho, var, X, Wt, Mrow, xc, fine_k)) flags |= kFlagAdmmNumerical;
+      if (gram_output<SH>(M, vbuf, lane, a.rho, var, X, Wt, Mrow, xc, gdiag, fine_k)) flags |= kFlagAdmmNumerical;
       t4 = wall_clock64();
       ph_p3 = t4 - t3;
     }
@@ -1708,9 +1767,24 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     // reference's own pivoted one fails over to its COD (fcc_qp.cpp:164-166).  Where W is singular
     // to working precision (a pivot <= kPresolveMinPivot: K is singular, the reference's COD gives
     // the minimum-norm solution) the instance goes to the device COD fallback, as before.
+    // Since round 4 the system W x0 = x_c is solved by conjugate gradients on the rows of rho G this wave holds
+    // anyway (cg_presolve: a dozen mat-vecs instead of a factorisation by tiles and two sweeps), and the direct
+    // factorisation below is what runs when CG declines or fails: W's diagonal says "singular", a search direction
+    // finds a vanishing eigenvalue, or the residual does not come down in n - m + 10 steps.
+    bool presolved = false;
     if (!a.warm_start) {
-      using SW = typename SH::Reduced;
       flags |= kFlagPresolveRan;
+#ifndef FCCQP_PRESOLVE_DIRECT
+      presolved = cg_presolve<SH>(vbuf, lane, isvar, var, Mrow, xc, gdiag, x);
+      if (!presolved) {          // the direct path reads x_c from vbuf[0..n), which carried CG's search directions
+        lds_fence();
+        if (isvar) vbuf[vi] = xc;
+        lds_fence();
+      }
+#endif
+    }
+    if (!a.warm_start && !presolved) {
+      using SW = typename SH::Reduced;
       // W arrives as register tiles from the Gram product; its factor goes to LDS (over the rho G image:
       // row `var` of rho G is in registers by now) for the two triangular sweeps
       const long long tw = wall_clock64();
@@ -1740,6 +1814,8 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       lds_fence();
       x = isvar ? vbuf[vi] : 0.0;
       lds_fence();
+    }
+    if (!a.warm_start) {
       const long long t5 = wall_clock64();
       ph_solve = t5 - t4;
       t4 = t5;

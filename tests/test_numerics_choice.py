@@ -5,7 +5,9 @@ triangular solves per ADMM iteration (/root/reference/src/fcc_qp.cpp:68,86).  Th
 (1) an unpivoted LDL^T in natural order, (2) x = x_c + (rho G) w with
 G = (K_rho^-1)[0:n,0:n] built once from that factorisation, and -- the fused kernel -- (3) the
 presolve x0 = (K^-1 [-b; b_eq]).head(n) (fcc_qp.cpp:159-178) as x0 = (I - rho G)^-1 x_c (Woodbury
-on K = K_rho - rho E E^T), i.e. without ever factorising K.  This test restates (1)+(2)+(3) in
+on K = K_rho - rho E E^T), i.e. without ever factorising K -- since round 4 by conjugate gradients on W = I - rho G
+(cg_presolve in fccqp_fused_impl.h: at most n - m + 1 distinct eigenvalues, a dozen mat-vecs), with the factorisation of
+W as the fallback.  This test restates (1)+(2)+(3) in
 numpy and compares against the oracle (Eigen's order, its own presolve, its COD where its LDLT
 fails): agreement is at rounding level, far inside the stated 1e-6 parity tolerance -- the evidence
 behind the kernel design, runnable without a GPU."""
@@ -33,7 +35,29 @@ def ldl_solve(L, D, r):
     return sl.solve_triangular(L.T, y, lower=False, unit_diagonal=True)
 
 
-def kernel_algorithm(qp, opts, dims, woodbury=True):
+def cg_presolve(W, xc, n, m):
+    """cg_presolve of fccqp_fused_impl.h restated: x = 0 start, relative residual 1e-13, n - m + 10 steps at most,
+    None where the device code declines (singular diagonal, vanishing Rayleigh quotient, no convergence)."""
+    if np.min(np.diag(W)) <= 1e-10:
+        return None, 0
+    x = np.zeros(n); r = xc.copy(); p = xc.copy(); rs = r @ r; bb = rs
+    if bb == 0.0:
+        return x, 0
+    for it in range(1, (n - m if n > m else n) + 11):
+        wp = W @ p
+        pwp = p @ wp
+        if not pwp > 1e-10 * rs:
+            return None, it
+        alpha = rs / pwp
+        x = x + alpha * p; r = r - alpha * wp
+        rs_new = r @ r
+        if rs_new <= 1e-26 * bb:
+            return x, it
+        p = r + (rs_new / rs) * p; rs = rs_new
+    return None, it
+
+
+def kernel_algorithm(qp, opts, dims, woodbury=True, cg=False, stats=None):
     n, m, nc, s = dims
     Q, A, b, beq = qp["Q"], qp["A_eq"], qp["b"], qp["b_eq"]
     lb, ub, mus, rho = qp["lb"], qp["ub"], qp["friction_coeffs"], opts["rho"]
@@ -46,9 +70,15 @@ def kernel_algorithm(qp, opts, dims, woodbury=True):
     xc = ldl_solve(L, D, rhs)[:n]
     if woodbury:                                                     # fused kernel: x0 = (I - rho G)^-1 x_c
         W = np.tril(np.eye(n) - M); W = W + np.tril(W, -1).T         # the kernel reads the lower triangle
-        Lw, Dw = ldl_natural(W)
-        assert Dw.min() > 1e-10                                      # kPresolveMinPivot
-        x = ldl_solve(Lw, Dw, xc)
+        x = None
+        if cg:                                                       # round 4: conjugate gradients first
+            x, its = cg_presolve(W, xc, n, m)
+            if stats is not None:
+                stats.append((its, x is not None))
+        if x is None:
+            Lw, Dw = ldl_natural(W)
+            assert Dw.min() > 1e-10                                  # kPresolveMinPivot
+            x = ldl_solve(Lw, Dw, xc)
     else:                                                            # generic kernel: direct LDL^T of K
         L0, D0 = ldl_natural(K)
         x = ldl_solve(L0, D0, rhs)[:n]
@@ -72,16 +102,21 @@ def test_natural_order_and_explicit_g_match_the_reference_order(oracle):
              (dict(max_iter=1000, rho=1e-2, eps_fcone=1e-6, eps_bound=1e-6), "W-sat"),
              (dict(max_iter=200, rho=1e-3, eps_fcone=1e-4, eps_bound=1e-4), "W-mix")]
     worst = 0.0
+    stats = []
     for opts, wl in cases:
         B = P.workload(wl, 6, P.WALKING)
         z_ref, it_ref, _, _ = oracle.solve_batch(dims, opts, *B.arrays(), nthreads=2)
         for i in range(B.batch):
-            for wb in (True, False):
-                z, nit = kernel_algorithm(B.instance(i), opts, dims, woodbury=wb)
+            for wb, cg in ((True, True), (True, False), (False, False)):
+                z, nit = kernel_algorithm(B.instance(i), opts, dims, woodbury=wb, cg=cg, stats=stats)
                 err = np.max(np.abs(z - z_ref[i])) / (1 + np.max(np.abs(z_ref[i])))
                 worst = max(worst, err)
                 assert nit == it_ref[i]
     assert worst < 1e-10, worst          # observed ~4e-13
+    # conjugate gradients converged on every instance within the cap of n - m + 10 steps (W has n - m + 1 = 23 distinct
+    # eigenvalues; 11-13 steps at the harness rho, up to 25 at rho = 1e-2, where cond(W) is 1e4), far fewer than n
+    assert stats and all(ok for _, ok in stats) and max(its for its, _ in stats) <= 22 + 10, stats
+    assert min(its for its, _ in stats) <= 13
 
 
 def test_woodbury_presolve_on_semidefinite_costs(oracle):
@@ -95,6 +130,26 @@ def test_woodbury_presolve_on_semidefinite_costs(oracle):
         z_ref, it_ref, det, _ = oracle.solve_batch(dims, opts, *B.arrays(), nthreads=2)
         for i in range(B.batch):
             assert det[i].presolve_ldlt_info == 1
-            z, nit = kernel_algorithm(B.instance(i), opts, dims, woodbury=True)
-            assert nit == it_ref[i]
-            assert np.max(np.abs(z - z_ref[i])) <= 1e-9 * (1 + np.max(np.abs(z_ref[i])))
+            for cg in (False, True):
+                z, nit = kernel_algorithm(B.instance(i), opts, dims, woodbury=True, cg=cg)
+                assert nit == it_ref[i]
+                assert np.max(np.abs(z - z_ref[i])) <= 1e-9 * (1 + np.max(np.abs(z_ref[i])))
+
+
+def test_cg_presolve_declines_where_the_direct_path_would_call_k_singular():
+    """A variable without cost or constraint: W has a zero diagonal entry (and x_c a zero there, so the system is even
+    consistent) -- conjugate gradients would converge without noticing; the diagonal test hands the instance to the
+    direct path, whose pivot rule sends it to the COD pass as the reference's LDLT failure does."""
+    dims = P.WALKING.ctor_args
+    n, m = dims[0], dims[1]
+    qp = {k: np.array(v, copy=True) for k, v in P.workload("W-sat", 1, P.WALKING).instance(0).items()}
+    j = 25
+    qp["Q"][j, :] = 0.0; qp["Q"][:, j] = 0.0; qp["A_eq"][:, j] = 0.0; qp["b"][j] = 0.0
+    rho = P.HARNESS_OPTIONS["rho"]
+    K = np.zeros((n + m, n + m)); K[:n, :n] = qp["Q"] + rho * np.eye(n); K[n:, :n] = qp["A_eq"]; K[:n, n:] = qp["A_eq"].T
+    Kinv = np.linalg.inv(K)
+    W = np.eye(n) - rho * Kinv[:n, :n]
+    xc = (Kinv @ np.r_[-qp["b"], qp["b_eq"]])[:n]
+    assert abs(W[j, j]) < 1e-10 and abs(xc[j]) < 1e-12
+    x, its = cg_presolve(W, xc, n, m)
+    assert x is None and its == 0

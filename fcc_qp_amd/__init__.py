@@ -26,7 +26,7 @@ try:
     from .fcc_qp_solver import (  # noqa: F401
         FCCQP, FCCQPBatch, FCCQPBatchSolution, FCCQPDetails, FCCQPError, FCCQPOptions, FCCQPSharded, FCCQPSolution,
         device_count, KERNEL_AUTO, KERNEL_COOP, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_GENERIC, FLAG_ADMM_NUMERICAL,
-        FLAG_EQ_RESIDUAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD, FLAG_PRESOLVE_NUMERICAL, FLAG_PRESOLVE_RAN)
+        FLAG_EQ_RESIDUAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_CG, FLAG_PRESOLVE_COD, FLAG_PRESOLVE_NUMERICAL, FLAG_PRESOLVE_RAN)
 except ImportError as exc:  # fail loudly: the HIP extension IS the product
     raise ImportError(
         "fcc_qp_amd: the native extension (fcc_qp_amd/libfccqp_hip.so + fcc_qp_solver*.so) is not "

@@ -150,6 +150,7 @@ constexpr int kFlagAdmmNumerical = 4;
 constexpr int kFlagEqualityOnly = 8;
 constexpr int kFlagPresolveCod = 16;
 constexpr int kFlagEqResidual = 32;
+constexpr int kFlagPresolveCg = 64;
 
 // ---- generic kernel (fccqp_generic.hip) -----------------------------------------------------
 // Largest KKT size N = n + m the generic kernel handles (8 register slots x 64 lanes; the reference's

@@ -401,7 +401,7 @@ using d4 = double __attribute__((ext_vector_type(4)));
 template <class SH>
 __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int lane, const double rho, const int grow,
                                             const d4 (&X)[(SH::N1 + 15) / 16][kWave / 16],
-                                            d4 (&Wt)[(SH::n + 15) / 16][(SH::n + 15) / 16], double (&Mrow)[SH::n],
+                                            double (&Mrow)[SH::n],
                                             double &xc, double &gdiag, long long *fine = nullptr) {
   constexpr int N = SH::N1, n = SH::n, NRB = (N + 15) / 16, NW = (n + 15) / 16, NB = SH::kBorder;
   const int col = lane & 15, grp = lane >> 4;
@@ -577,13 +577,7 @@ __device__ __forceinline__ bool gram_output(lds_f64 *M, lds_f64 *vbuf, const int
           for (int bb = 0; bb < NB; ++bb) gv = fma(corr_r[I][r][bb], zc[bb], gv);
         }
         g4[r] = rho * gv;
-        const bool inside = interior || (row < n && c < n);
         if (NB == 0 && J == cbd && c == n && row < n) vbuf[row] = Gt[I][J][r];     // x_c
-        if (J < NW) {
-          const double unit = (I == J && row == c) ? 1.0 : 0.0;
-          if (interior) Wt[I][J][r] = unit - g4[r];
-          else Wt[I][J][r] = select_lanes(__builtin_amdgcn_ballot_w64(inside), unit - g4[r], unit);   // (VOP3 select)
-        }
       }
       if (interior || c < n) {
 #pragma unroll
@@ -982,6 +976,29 @@ __device__ __forceinline__ bool tile_factor_forward(lds_f64 *M, lds_f64 *vbuf, c
     }
   });
   return bad;
+}
+
+// upper tiles of W = I - rho G in accumulator layout from the rho G image gram_output left in LDS (row stride
+// Shape::kImgStride), rows / columns past n the identity
+template <class SH>
+__device__ __forceinline__ void w_tiles_from_image(const lds_f64 *M, const int lane, d4 (&Wt)[(SH::n + 15) / 16][(SH::n + 15) / 16]) {
+  constexpr int n = SH::n, NW = (n + 15) / 16;
+  const int col = lane & 15, grp = lane >> 4;
+#pragma unroll
+  for (int I = 0; I < NW; ++I) {
+#pragma unroll
+    for (int J = I; J < NW; ++J) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + grp + 4 * r, c = 16 * J + col;
+        const bool inside = row < n && c < n;
+        const double g = M[(inside ? row : 0) * SH::kImgStride + (inside ? c : 0)];
+        const double unit = (I == J && row == c) ? 1.0 : 0.0;
+        Wt[I][J][r] = inside ? unit - g : unit;
+      }
+    }
+  }
+  lds_fence();
 }
 
 // W = U^T D U by register tiles (the presolve, see fused_kernel), same scheme as tile_factor_forward without
@@ -1724,7 +1741,6 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
     double xc, gdiag;
     long long t4;
     constexpr int NW = (n + 15) / 16;
-    d4 Wt[NW][NW];   // upper tiles of W = I - rho G, from the Gram product to the presolve
     {
       constexpr int NRB = (SH::N1 + 15) / 16;
       d4 C[NRB][NRB], X[NRB][kWave / 16];
@@ -1744,7 +1760,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       if (tile_factor_forward<SH>(M, vbuf, lane, C, X, fine_k)) flags |= kFlagAdmmNumerical;
       const long long t3 = wall_clock64();
       ticks = t3 - t0;
-      if (gram_output<SH>(M, vbuf, lane, a.rho, var, X, Wt, Mrow, xc, gdiag, fine_k)) flags |= kFlagAdmmNumerical;
+      if (gram_output<SH>(M, vbuf, lane, a.rho, var, X, Mrow, xc, gdiag, fine_k)) flags |= kFlagAdmmNumerical;
       t4 = wall_clock64();
       ph_p3 = t4 - t3;
     }
@@ -1776,6 +1792,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       flags |= kFlagPresolveRan;
 #ifndef FCCQP_PRESOLVE_DIRECT
       presolved = cg_presolve<SH>(vbuf, lane, isvar, var, Mrow, xc, gdiag, x);
+      if (presolved) flags |= kFlagPresolveCg;
       if (!presolved) {          // the direct path reads x_c from vbuf[0..n), which carried CG's search directions
         lds_fence();
         if (isvar) vbuf[vi] = xc;
@@ -1788,6 +1805,11 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
       // W arrives as register tiles from the Gram product; its factor goes to LDS (over the rho G image:
       // row `var` of rho G is in registers by now) for the two triangular sweeps
       const long long tw = wall_clock64();
+      // the upper tiles of W = I - rho G (identity-padded to whole tiles), back out of the rho G image in LDS, which
+      // conjugate gradients left alone (through round 3 gram_output produced them on every solve; now only this path
+      // wants them)
+      d4 Wt[NW][NW];
+      w_tiles_from_image<SH>(M, lane, Wt);
       const bool wbad = tile_factor_store<SH>(M, lane, kPresolveMinPivot, Wt, fine_w);
 #ifdef FCCQP_FINE_STAMPS
       fine_w[1] = wall_clock64() - tw;       // the whole factorisation of W

@@ -354,4 +354,5 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
   m.attr("FLAG_EQUALITY_ONLY") = (int)FCCQP_FLAG_EQUALITY_ONLY;
   m.attr("FLAG_PRESOLVE_COD") = (int)FCCQP_FLAG_PRESOLVE_COD;
   m.attr("FLAG_EQ_RESIDUAL") = (int)FCCQP_FLAG_EQ_RESIDUAL;
+  m.attr("FLAG_PRESOLVE_CG") = (int)FCCQP_FLAG_PRESOLVE_CG;
 }

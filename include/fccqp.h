@@ -66,6 +66,10 @@ enum {
   FCCQP_FLAG_EQUALITY_ONLY = 8,         /* nc == 0 and all bounds infinite: no ADMM (:132-133)   */
   FCCQP_FLAG_PRESOLVE_COD = 16,         /* x0 came from the device COD fallback (min-norm least
                                            squares, fcc_qp.cpp:165,176): z IS comparable again   */
+  FCCQP_FLAG_PRESOLVE_CG = 64,          /* the presolve's system (I - rho G) x0 = x_c was solved by conjugate gradients
+                                           (one-wave kernel, cold start; same x0 to ~1e-13).  Clear with PRESOLVE_RAN
+                                           set: the direct factorisation ran (other kernels; or CG declined: singular
+                                           diagonal, vanishing curvature, no convergence in n - m + 10 steps)           */
   FCCQP_FLAG_EQ_RESIDUAL = 32           /* self-check (fccqp_set_self_check): the returned z is not finite, or
                                            |A_eq z - b_eq| exceeds 1e-6 of the terms of some row.  Every primal
                                            iterate is the head of a KKT solve (fcc_qp.cpp:86-87), so this never

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "fccqp.h")
 
 OK, ERR_INVALID_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_FRICTION, ERR_NOT_SOLVED, ERR_UNSUPPORTED = range(9)
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_COOP = 0, 1, 2, 3, 4
-FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD, FLAG_EQ_RESIDUAL = 1, 2, 4, 8, 16, 32
+FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD, FLAG_EQ_RESIDUAL, FLAG_PRESOLVE_CG = 1, 2, 4, 8, 16, 32, 64
 TIMING_NONE, TIMING_DEVICE_EVENTS, TIMING_HOST_CLOCK = 0, 1, 2
 
 

@@ -114,3 +114,44 @@ def test_last_timing_says_how_it_was_measured():
     small.Solve(*P.workload("W-sat", 2, P.WALKING).arrays())
     assert small.LastTiming()[1] == "host_clock"
     assert F.FLAG_EQ_RESIDUAL == CAPI.FLAG_EQ_RESIDUAL == 32
+
+
+def test_presolve_path_is_reported():
+    """One-wave kernel, cold start: the presolve's system (I - rho G) x0 = x_c is solved by conjugate gradients
+    (FLAG_PRESOLVE_CG) -- on W-sat, W-mix and the semi-definite W-psd alike --, EXCEPT where CG declines and the direct
+    factorisation of W takes over with its own rules: a variable without cost or constraint (singular diagonal -> the
+    COD pass, as the reference's LDLT failure), and a rho so large that W is too ill-conditioned to converge in
+    n - m + 10 steps.  Warm starts skip the presolve; the generic kernel has no CG path.  z agrees between the two
+    presolves to rounding."""
+    from tests.test_gpu_parity import _dead_variable
+    shape = P.WALKING
+    for wl in ("W-sat", "W-mix", "W-psd"):
+        B = P.workload(wl, 16, shape)
+        s = CAPI.Solver(*shape.ctor_args, batch=16); s.set_options(**P.HARNESS_OPTIONS)
+        s.solve_ok(*B.arrays())
+        fl = _flags(s)
+        assert np.all(fl & CAPI.FLAG_PRESOLVE_RAN) and np.all(fl & CAPI.FLAG_PRESOLVE_CG), (wl, fl)
+        z_cg, _ = s.solution()
+        s.set_kernel(CAPI.KERNEL_GENERIC)
+        s.solve_ok(*B.arrays())
+        assert not np.any(_flags(s) & CAPI.FLAG_PRESOLVE_CG)
+        z_dir, _ = s.solution()
+        assert np.max(np.abs(z_cg - z_dir)) <= 1e-9 * (1 + np.max(np.abs(z_dir))), wl
+        s.set_kernel(CAPI.KERNEL_AUTO)
+        s.set_warm_start(True)
+        s.solve_ok(*B.arrays())
+        assert not np.any(_flags(s) & (CAPI.FLAG_PRESOLVE_RAN | CAPI.FLAG_PRESOLVE_CG))
+    # CG declines: dead variables (instances 1 and 4), the rest of the batch is unaffected
+    base = P.workload("W-sat", 6, shape)
+    qps = [base.instance(i) for i in range(6)]
+    qps[1] = _dead_variable(qps[1], 25); qps[4] = _dead_variable(qps[4], 31)
+    s = CAPI.Solver(*shape.ctor_args, batch=6); s.set_options(**P.HARNESS_OPTIONS)
+    s.solve_ok(*P.stack(qps).arrays())
+    fl = _flags(s)
+    assert [bool(f & CAPI.FLAG_PRESOLVE_CG) for f in fl] == [True, False, True, True, False, True]
+    assert [bool(f & CAPI.FLAG_PRESOLVE_COD) for f in fl] == [False, True, False, False, True, False]
+    # CG does not converge: rho = 100 (cond(W) ~ 1e8) -> the factorisation of W, no flag, same accuracy as before
+    s2 = CAPI.Solver(*shape.ctor_args, batch=6); s2.set_options(max_iter=0, rho=100.0, eps_fcone=1e-6, eps_bound=1e-6)
+    s2.solve_ok(*base.arrays())
+    fl = _flags(s2)
+    assert np.all(fl & CAPI.FLAG_PRESOLVE_RAN) and not np.any(fl & CAPI.FLAG_PRESOLVE_CG), fl

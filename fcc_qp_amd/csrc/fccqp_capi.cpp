@@ -208,9 +208,9 @@ int order_after_previous(fccqp_solver *s, hipStream_t stream) {
   return FCCQP_OK;
 }
 
-int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *dA,
-            const double *dbeq, const double *dmu, const double *dlb, const double *dub,
-            hipStream_t stream, bool qa_f32 = false, bool defer_fallback = false) {
+int enqueue_impl(fccqp_solver *s, const double *dQ, const double *db, const double *dA,
+                 const double *dbeq, const double *dmu, const double *dlb, const double *dub,
+                 hipStream_t stream, bool qa_f32, bool defer_fallback) {
   s->hres_fresh = false;
   s->fb_deferred = false;
   s->quiesced = false;
@@ -347,6 +347,31 @@ int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *d
   return FCCQP_OK;
 }
 
+// A solve that failed part-way may have a kernel running on `stream`, a fallback list nobody is going to consume and
+// no end event for the next solve to wait on.  Leave the handle as before its first solve (GetSolution answers
+// FCCQP_ERR_NOT_SOLVED; the warm-start state is whatever the kernels left): the stream drained, both list counters
+// cleared, nothing pending.  Keeps the message of the failure.
+void reset_after_failed_solve(fccqp_solver *s, hipStream_t stream) {
+  const std::string msg = s->err;
+  if (s->dfb_count) (void)hipMemsetAsync(s->dfb_count, 0, 2 * sizeof(int), stream);
+  (void)hipStreamSynchronize(stream);
+  (void)hipGetLastError();
+  s->fb_deferred = false;
+  s->hres_fresh = false;
+  s->solved = false;
+  s->quiesced = true;
+  s->host_device_ms = 0.f;
+  s->err = msg;
+}
+
+int enqueue(fccqp_solver *s, const double *dQ, const double *db, const double *dA,
+            const double *dbeq, const double *dmu, const double *dlb, const double *dub,
+            hipStream_t stream, bool qa_f32 = false, bool defer_fallback = false) {
+  const int rc = enqueue_impl(s, dQ, db, dA, dbeq, dmu, dlb, dub, stream, qa_f32, defer_fallback);
+  if (rc != FCCQP_OK) reset_after_failed_solve(s, stream);
+  return rc;
+}
+
 // Host wait for a short solve: poll the stream instead of sleeping on its completion signal (the blocking wait
 // costs a wake-up of 10-20 us, a fifth of a one-QP solve); falls back to the blocking wait after ~2 ms.
 hipError_t spin_synchronize(hipStream_t stream) {
@@ -376,17 +401,11 @@ int run_deferred_fallback(fccqp_solver *s, hipStream_t stream) {
 }
 
 // A failure after enqueue(.., defer_fallback = true): no end event was recorded and the main kernel may have appended
-// to the fallback list that nobody is going to consume.  Leave the handle as after a finished solve with empty
-// lists: both counters cleared, nothing pending, nothing to wait for.
+// to the fallback list that nobody is going to consume (reset_after_failed_solve).
 int abandon_deferred(fccqp_solver *s, hipStream_t stream, const char *what, hipError_t e) {
-  (void)hipMemsetAsync(s->dfb_count, 0, 2 * sizeof(int), stream);
-  s->fb_deferred = false;
-  (void)hipStreamSynchronize(stream);
-  (void)hipGetLastError();
-  s->hres_fresh = false;
-  s->quiesced = true;
-  s->host_device_ms = 0.f;
-  return fail(s, FCCQP_ERR_HIP, what, e);
+  const int rc = fail(s, FCCQP_ERR_HIP, what, e);
+  reset_after_failed_solve(s, stream);
+  return rc;
 }
 
 }  // namespace
@@ -689,14 +708,7 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
     const bool defer = wait && s->hres_block != nullptr;      // flags come back with the results: look before launching the list pass
     const auto t_launch = std::chrono::high_resolution_clock::now();
     rc = enqueue(s, at(0), at(1), at(2), at(3), at(4), at(5), at(6), st, /*qa_f32=*/false, defer);
-    if (rc != FCCQP_OK) {
-      if (defer) {           // (the main kernel may already run: same clean-up as for a failure behind it)
-        const std::string msg = s->err;
-        (void)abandon_deferred(s, st, "enqueue", hipSuccess);
-        s->err = msg;
-      }
-      return rc;
-    }
+    if (rc != FCCQP_OK) return rc;
     if (!wait) {
       s->last_solve_wall = 0.0;
       return FCCQP_OK;
@@ -715,9 +727,7 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
       if (flagged) {          // rare: the COD pass, then the results again
         rc = run_deferred_fallback(s, st);
         if (rc != FCCQP_OK) {
-          const std::string msg = s->err;
-          (void)abandon_deferred(s, st, "fallback pass of a synchronous solve", hipSuccess);
-          s->err = msg;
+          reset_after_failed_solve(s, st);
           return rc;
         }
         he = hipMemcpyAsync(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost, st);
@@ -735,23 +745,29 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
     s->last_solve_wall = std::chrono::duration<double>(t1s - t0).count();  // src/fcc_qp.cpp:188-190
     return FCCQP_OK;
   }
-  HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(double) * B * n * n, hipMemcpyHostToDevice, st));
-  HIP_TRY(s, hipMemcpyAsync(s->db, b, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-  if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(double) * B * m * n, hipMemcpyHostToDevice, st));
-  if (m) HIP_TRY(s, hipMemcpyAsync(s->dbeq, b_eq, sizeof(double) * B * m, hipMemcpyHostToDevice, st));
-  if (nm) {
-    if ((size_t)n_friction == nm) {
-      HIP_TRY(s, hipMemcpyAsync(s->dmu, friction_coeffs, sizeof(double) * B * nm, hipMemcpyHostToDevice, st));
-    } else {  // keep the first nc/3 of every instance's row
-      HIP_TRY(s, hipMemcpy2DAsync(s->dmu, sizeof(double) * nm, friction_coeffs,
-                                  sizeof(double) * (size_t)n_friction, sizeof(double) * nm, B,
-                                  hipMemcpyHostToDevice, st));
+  rc = [&]() -> int {
+    HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(double) * B * n * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s, hipMemcpyAsync(s->db, b, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+    if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(double) * B * m * n, hipMemcpyHostToDevice, st));
+    if (m) HIP_TRY(s, hipMemcpyAsync(s->dbeq, b_eq, sizeof(double) * B * m, hipMemcpyHostToDevice, st));
+    if (nm) {
+      if ((size_t)n_friction == nm) {
+        HIP_TRY(s, hipMemcpyAsync(s->dmu, friction_coeffs, sizeof(double) * B * nm, hipMemcpyHostToDevice, st));
+      } else {  // keep the first nc/3 of every instance's row
+        HIP_TRY(s, hipMemcpy2DAsync(s->dmu, sizeof(double) * nm, friction_coeffs,
+                                    sizeof(double) * (size_t)n_friction, sizeof(double) * nm, B,
+                                    hipMemcpyHostToDevice, st));
+      }
     }
+    HIP_TRY(s, hipMemcpyAsync(s->dlb, lb, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s, hipMemcpyAsync(s->dub, ub, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+    return enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st);
+  }();
+  if (rc != FCCQP_OK) {
+    // the caller's buffers are borrowed for the copies: none of them may still be running when the error returns
+    reset_after_failed_solve(s, st);
+    return rc;
   }
-  HIP_TRY(s, hipMemcpyAsync(s->dlb, lb, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-  HIP_TRY(s, hipMemcpyAsync(s->dub, ub, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-  rc = enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st);
-  if (rc != FCCQP_OK) return rc;
   if (!wait) {
     s->last_solve_wall = 0.0;   // reported as the kernel time, like a device-pointer solve
     return FCCQP_OK;
@@ -804,15 +820,19 @@ int fccqp_solve_async_f32(fccqp_solver *s, const float *Q, const float *b, const
   const float *const hv[5] = {b, b_eq, friction_coeffs, lb, ub};
   const size_t cnt[5] = {B * n, B * m, B * nm, B * n, B * n};
   if (B * (3 * n + m + nm) > B * n * n) return fail(s, FCCQP_ERR_UNSUPPORTED, "shape too small for the float staging layout");
-  HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));
-  if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(float) * B * m * n, hipMemcpyHostToDevice, st));
-  for (int i = 0; i < 5; ++i)
-    if (cnt[i]) HIP_TRY(s, hipMemcpyAsync(dv[i], hv[i], sizeof(float) * cnt[i], hipMemcpyHostToDevice, st));
-  const float *const src[5] = {dv[0], dv[1], dv[2], dv[3], dv[4]};
-  double *const dst[5] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub};
-  HIP_TRY(s, fccqp::launch_widen5(src, dst, cnt, st));
-  s->last_solve_wall = 0.0;   // reported as the kernel time, like a device-pointer solve
-  return enqueue(s, s->dQ, s->wb, s->dA, s->wbeq, s->wmu, s->wlb, s->wub, st, /*qa_f32=*/true);
+  rc = [&]() -> int {
+    HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));
+    if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(float) * B * m * n, hipMemcpyHostToDevice, st));
+    for (int i = 0; i < 5; ++i)
+      if (cnt[i]) HIP_TRY(s, hipMemcpyAsync(dv[i], hv[i], sizeof(float) * cnt[i], hipMemcpyHostToDevice, st));
+    const float *const src[5] = {dv[0], dv[1], dv[2], dv[3], dv[4]};
+    double *const dst[5] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub};
+    HIP_TRY(s, fccqp::launch_widen5(src, dst, cnt, st));
+    s->last_solve_wall = 0.0;   // reported as the kernel time, like a device-pointer solve
+    return enqueue(s, s->dQ, s->wb, s->dA, s->wbeq, s->wmu, s->wlb, s->wub, st, /*qa_f32=*/true);
+  }();
+  if (rc != FCCQP_OK) reset_after_failed_solve(s, st);      // (no copy out of the caller's buffers outlives the error)
+  return rc;
 }
 
 int fccqp_solve_device_f32(fccqp_solver *s, const float *dQ, const float *db, const float *dA_eq,
@@ -856,19 +876,24 @@ int fccqp_solve_f32(fccqp_solver *s, const float *Q, const float *b, const float
   if (rc != FCCQP_OK) return rc;
   // Q and A_eq travel and stay as float (in the front half of the f64 staging buffers); the small
   // vectors are widened here on the host
-  HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));
-  if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(float) * B * m * n, hipMemcpyHostToDevice, st));
   std::vector<double> wb(b, b + B * n), wbeq(b_eq, b_eq + (m ? B * m : 0)), wlb(lb, lb + B * n),
       wub(ub, ub + B * n), wmu(B * nm);
   for (size_t i = 0; i < B; ++i)
     for (size_t c = 0; c < nm; ++c) wmu[i * nm + c] = (double)friction_coeffs[i * (size_t)n_friction + c];
-  HIP_TRY(s, hipMemcpyAsync(s->db, wb.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-  if (m) HIP_TRY(s, hipMemcpyAsync(s->dbeq, wbeq.data(), sizeof(double) * B * m, hipMemcpyHostToDevice, st));
-  if (nm) HIP_TRY(s, hipMemcpyAsync(s->dmu, wmu.data(), sizeof(double) * B * nm, hipMemcpyHostToDevice, st));
-  HIP_TRY(s, hipMemcpyAsync(s->dlb, wlb.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-  HIP_TRY(s, hipMemcpyAsync(s->dub, wub.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-  rc = enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st, /*qa_f32=*/true);
-  if (rc != FCCQP_OK) return rc;
+  rc = [&]() -> int {
+    HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));
+    if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(float) * B * m * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s, hipMemcpyAsync(s->db, wb.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+    if (m) HIP_TRY(s, hipMemcpyAsync(s->dbeq, wbeq.data(), sizeof(double) * B * m, hipMemcpyHostToDevice, st));
+    if (nm) HIP_TRY(s, hipMemcpyAsync(s->dmu, wmu.data(), sizeof(double) * B * nm, hipMemcpyHostToDevice, st));
+    HIP_TRY(s, hipMemcpyAsync(s->dlb, wlb.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(s, hipMemcpyAsync(s->dub, wub.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+    return enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st, /*qa_f32=*/true);
+  }();
+  if (rc != FCCQP_OK) {
+    reset_after_failed_solve(s, st);      // (drains the stream: the widened vectors above outlive their copies)
+    return rc;
+  }
   HIP_TRY(s, hipStreamSynchronize(st));   // also keeps the host vectors alive until the copies ran
   const auto t1 = std::chrono::high_resolution_clock::now();
   s->last_solve_wall = std::chrono::duration<double>(t1 - t0).count();

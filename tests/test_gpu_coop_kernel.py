@@ -178,3 +178,24 @@ def test_coop_refused_for_an_unlisted_shape():
     s.set_kernel(CAPI.KERNEL_COOP)
     B = random_batch((10, 4, 3, 2), 2, seed=1)
     assert s.solve(*B.arrays()) == CAPI.ERR_UNSUPPORTED
+
+
+def test_a_refused_solve_leaves_no_stale_solution_and_the_handle_usable():
+    """A solve that fails after an earlier good one: GetSolution must not hand the earlier z out as this solve's (it
+    answers FCCQP_ERR_NOT_SOLVED), and the handle solves again once the request is one it can serve."""
+    shape = (10, 4, 3, 2)
+    s = CAPI.Solver(*shape, batch=2)
+    s.set_options(**P.HARNESS_OPTIONS)
+    B = random_batch(shape, 2, seed=1)
+    s.solve_ok(*B.arrays())
+    z0, d0 = s.solution()
+    s.set_kernel(CAPI.KERNEL_COOP)
+    assert s.solve(*B.arrays()) == CAPI.ERR_UNSUPPORTED
+    z = np.zeros((2, 10))
+    d = (CAPI.Details * 2)()
+    assert s.L.fccqp_get_solution(s.h, z.ctypes.data_as(CAPI.C.POINTER(CAPI.C.c_double)), d) == CAPI.ERR_NOT_SOLVED
+    s.set_kernel(CAPI.KERNEL_AUTO)
+    s.solve_ok(*B.arrays())
+    z1, d1 = s.solution()
+    assert np.array_equal(z0, z1) and [x.n_iter for x in d0] == [x.n_iter for x in d1]
+

@@ -53,17 +53,27 @@ def build_lib(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in ("fccqp_capi.cpp", "fccqp_generic.hip", "fccqp_fused.hip",
                                             "fccqp_fused_f32.hip", "fccqp_fused_split.hip", "fccqp_coop.hip",
                                             "fccqp_check.hip")]
-    deps = srcs + [os.path.join(CSRC, "fccqp_device.h"), os.path.join(CSRC, "fccqp_fused_impl.h"),
-                          os.path.join(CSRC, "fccqp_coop_impl.h"), os.path.join(CSRC, "coop_shapes.def"),
-                          os.path.join(CSRC, "fused_shapes.def"),
-                          os.path.join(CSRC, "fccqp_cod_impl.h"),
-                          os.path.join(ROOT, "include", "fccqp.h")]
+    def c(*names):
+        return [os.path.join(CSRC, x) for x in names]
+    # what each translation unit includes (the unrolled tile kernels take minutes: only what changed is recompiled)
+    fused_deps = c("fccqp_device.h", "fccqp_fused_impl.h", "fused_shapes.def")
+    own_deps = {
+        "fccqp_capi.cpp": c("fccqp_device.h") + [os.path.join(ROOT, "include", "fccqp.h")],
+        "fccqp_generic.hip": c("fccqp_device.h", "fccqp_cod_impl.h"),
+        "fccqp_fused.hip": fused_deps,
+        "fccqp_fused_f32.hip": fused_deps + c("fccqp_fused.hip"),
+        "fccqp_fused_split.hip": fused_deps,
+        "fccqp_coop.hip": c("fccqp_device.h", "fccqp_fused_impl.h", "fccqp_coop_impl.h", "coop_shapes.def"),
+        "fccqp_check.hip": c("fccqp_device.h"),
+    }
+    this_file = os.path.abspath(__file__)       # (the compiler flags live here)
+    deps = srcs + [d for v in own_deps.values() for d in v] + [this_file]
     if force or _newer(LIB, deps):
         objs = [os.path.splitext(src)[0] + ".o" for src in srcs]
 
         def compile_one(job):
             src, obj = job
-            if force or _newer(obj, deps):
+            if force or _newer(obj, [src, this_file] + own_deps[os.path.basename(src)]):
                 # the fully unrolled MFMA tile code (up to 13 row blocks) is larger than LLVM's default
                 # budget for `#pragma unroll`; left partly rolled it indexes register arrays dynamically
                 # fused kernel: loop headers on 256-byte boundaries -- its ADMM loop ran 5 % slower or faster

@@ -81,8 +81,10 @@ struct fccqp_solver {
   // per instance up to a full grid, bounded by 256 MiB of COD workspace (2 N^2 doubles per block).
   int fb_blocks = 1;
   // The list is empty for all but degenerate inputs, and a full grid of the generic kernel that finds it empty still
-  // costs 6.4 us of every solve (1024 workgroups with ~60 KB of LDS each to dispatch), 64 workgroups 3.7 us less.  Block 0 of
-  // every fallback launch leaves the length of its list in page-locked host memory (fb_seen, device alias fb_seen_dev);
+  // costs 6.4 us of every solve (1024 workgroups with ~60 KB of LDS each to dispatch), 64 workgroups 3.7 us less (8 or 1
+  // workgroups: no further gain, measured round 4).  Block 0 of
+  // a fallback launch that HAS a list leaves its length in page-locked host memory (fb_seen, device alias fb_seen_dev;
+  // the host clears the word when it has read it);
   // the next launches use the full grid while a recent one was non-empty (or nothing is known yet) and
   // kFbSmallGrid workgroups otherwise.  A performance heuristic only: the persistent workgroups walk the whole list
   // whatever their number.
@@ -306,8 +308,12 @@ int enqueue_impl(fccqp_solver *s, const double *dQ, const double *db, const doub
     // zeroes the other counter, which the next solve's main kernel will append to.
     int blocks = s->fb_blocks;
     if (s->fb_seen) {
-      if (*s->fb_seen != 0) s->fb_full_left = fccqp_solver::kFbFullFor;
-      else if (s->fb_full_left > 0) --s->fb_full_left;
+      if (*s->fb_seen != 0) {
+        s->fb_full_left = fccqp_solver::kFbFullFor;
+        *s->fb_seen = 0;          // (the device only ever writes non-zero lengths; one that lands right now is seen next time)
+      } else if (s->fb_full_left > 0) {
+        --s->fb_full_left;
+      }
       if (s->fb_full_left == 0 && blocks > fccqp_solver::kFbSmallGrid) blocks = fccqp_solver::kFbSmallGrid;
     }
     fccqp::KernelArgs b = a;

@@ -1865,9 +1865,10 @@ __global__ __launch_bounds__((kWave * waves_for<SLOTS, MAT_IN_LDS>())) void gene
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       *a.next_count = 0;
       // (list mode does not append: fb_list is null.  fb_count then points at a word of page-locked host memory in
-      // which the host finds, some time later, how long this launch's list was -- fccqp_capi.cpp sizes the NEXT
-      // fallback launch by it)
-      if (a.fb_count) *a.fb_count = total;
+      // which the host finds, some time later, that a launch had a list to walk and how long it was --
+      // fccqp_capi.cpp sizes the NEXT fallback launches by it.  An empty list, the rule, writes nothing: the store
+      // crosses PCIe and the end of the kernel waits for it.)
+      if (a.fb_count && total != 0) *a.fb_count = total;
     }
     for (int li = blockIdx.x; li < total; li += gridDim.x) run(a.inst_list[li], true);
   } else {

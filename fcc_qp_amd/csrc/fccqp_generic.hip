@@ -1227,6 +1227,9 @@ __device__ void helper_wave(const KernelArgs &a, double *lds, const int inst, co
       const bool wb = ldlt_factor_share<(SLOTS < 2 ? SLOTS : 2)>(M, n, lane, wave, WAVES, ctrl + 2, kPresolveMinPivot);
       if (lane == 0) ctrl[3 + wave] = wb ? 1.0 : 0.0;  // the n x n factorisation is shared like the KKT one
       workgroup_sync();                                 // B3: W is factorised (the solver wave solves alone)
+      // B4: ... and has solved.  Only where rho G goes into LDS next, over the factor of W the solver wave is
+      // still sweeping through (with G in the helpers' registers nobody writes LDS here)
+      if (!mv_regs) workgroup_sync();
     }
     if (mv_regs) {
       // rho G stays out of LDS: this wave's columns into registers (staged column-major, global / L2).
@@ -1619,6 +1622,13 @@ __device__ void solve_instance(const KernelArgs &a, double *lds, const int inst,
               xbar[t] = x[t]; lcbar[t] = x[t];           // :74-75
             }
             wave_sync();
+            if constexpr (WAVES > 1) {
+              // B4 (helper_wave): the helpers copy rho G into LDS over the factor of W -- not before this wave has
+              // solved with it.  (Found by tools/fuzz_parity.py in round 4: shapes with N > 128 whose LDS has room
+              // for G and w but not for the partial sums of a shared mat-vec, e.g. (89, 40), (94, 40), returned an x0
+              // swept through a half-overwritten factor on every cold start.)
+              if (!mv_regs) workgroup_sync();
+            }
           }
           if (!(WAVES > 1 && mv_regs)) {              // (four waves: the helpers keep G in registers)
             const int total = n * n;

@@ -178,7 +178,7 @@ class OracleFCCQP:
         Qa, Qp = _d(Q); ba, bp = _d(b); Aa, Ap = _d(A_eq); bea, bep = _d(b_eq)
         fa, fp = _d(friction_coeffs); la, lp = _d(lb); ua, up = _d(ub)
         if Qa.shape != (self.n, self.n) or ba.shape != (self.n,) or la.shape != (self.n,) \
-                or ua.shape != (self.n,) or Aa.reshape(self.m, -1).shape != (self.m, self.n) \
+                or ua.shape != (self.n,) or Aa.size != self.m * self.n \
                 or bea.shape != (self.m,):
             raise ValueError("shape mismatch")
         rc = self._L.fccqp_oracle_solve(self._h, Qp, bp, Ap, bep, fp, int(fa.size), lp, up)

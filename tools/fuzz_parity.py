@@ -1,0 +1,156 @@
+"""Randomised parity run: the HIP path (through the C ABI) against the CPU oracle on random shapes, options, kernels and
+inputs, cold and warm.  Test infrastructure like tests/: the oracle is the checker.
+    python tools/fuzz_parity.py [seconds] [seed]
+Prints one line per case that is notable (rel err > 1e-9, n_iter different, flags raised) and a summary; exit code 1
+if a case breaks the stated contract (tests/helpers.py: rel err <= 1e-6, |dn_iter| <= 1, on non-degenerate inputs).
+
+Cases: a listed (fused / cooperative) shape or a random one (generic kernel); any kernel that serves the shape; options
+rho 1e-6 .. 1, eps 1e-8 .. 1e-2, max_iter 0 .. 300; dense random QPs of varying conditioning with a random set of
+finite bounds (also on contact variables, also lb == ub), friction 0 .. 1.2, now and then a zero right-hand side, a
+contact with f_z pinned to zero, a variable without cost or constraint (singular K: the COD pass, compared loosely); batch
+1 .. 200; a second, warm-started solve of the same inputs (small batches, through the oracle's class)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fcc_qp_amd import problems as P
+from oracle import oracle as O
+from tests import capi as CAPI
+
+FUSED = [(60, 38, 12, 38), (12, 5, 6, 3), (12, 8, 6, 3), (32, 14, 6, 20), (32, 18, 6, 20), (12, 7, 6, 3), (24, 6, 15, 4)]
+COOP = [(114, 60, 24, 66), (60, 38, 12, 38), (70, 20, 9, 40), (32, 14, 6, 20), (20, 8, 6, 5)]
+
+
+def random_shape(rng):
+    n = int(rng.integers(3, 90))
+    m = int(rng.integers(0, min(n, 50)))
+    ncmax = min(n // 3, 8)
+    k = int(rng.integers(0, ncmax + 1))
+    nc = 3 * k
+    s = int(rng.integers(0, n - nc + 1))
+    return (n, m, nc, s)
+
+
+def random_batch(rng, dims, nb, singular):
+    n, m, nc, s = dims
+    Lq = rng.standard_normal((nb, n, n)) / np.sqrt(n)
+    delta = 10.0 ** rng.uniform(-3, 0.5)
+    Q = Lq @ np.transpose(Lq, (0, 2, 1)) + delta * np.eye(n)
+    if rng.random() < 0.3:                                   # badly scaled variables
+        sc = 10.0 ** rng.uniform(-1.5, 1.5, n)
+        Q = Q * sc[None, :, None] * sc[None, None, :]
+    A = rng.standard_normal((nb, m, n))
+    b = rng.standard_normal((nb, n)) * 10.0 ** rng.uniform(-1, 1)
+    beq = rng.standard_normal((nb, m)) * (0.0 if rng.random() < 0.1 else 0.3)
+    if singular:
+        # a variable without cost or constraint: K singular, K_rho regular (rho fills the zero on the diagonal) -- the
+        # reference's COD branch (fcc_qp.cpp:164-177), minimum-norm x0.  (Rank-deficient A_eq is NOT a parity case: K_rho
+        # is singular too, Eigen's LDLT keeps a rounding-level pivot and the reference's iterates are rounding noise.)
+        free = [j for j in range(n) if not (s <= j < s + nc)]
+        j = free[int(rng.integers(len(free)))] if free else 0
+        Q[:, j, :] = 0.0; Q[:, :, j] = 0.0; A[:, :, j] = 0.0; b[:, j] = 0.0
+    lb = np.full((nb, n), -np.inf); ub = np.full((nb, n), np.inf)
+    k = int(rng.integers(0, n + 1)) if rng.random() < 0.7 else 0
+    idx = rng.permutation(n)[:k]
+    w = 10.0 ** rng.uniform(-2, 0.5)
+    lb[:, idx] = -w * rng.uniform(0.1, 1.0, (nb, len(idx))); ub[:, idx] = w * rng.uniform(0.1, 1.0, (nb, len(idx)))
+    if k and rng.random() < 0.2:
+        ub[:, idx[0]] = lb[:, idx[0]]                        # lb == ub
+    if nc and rng.random() < 0.2:
+        lb[:, s + 2] = 0.0; ub[:, s + 2] = 0.0               # f_z pinned to zero: the zero-ray quirk's neighbourhood
+    mu = rng.uniform(0.0 if rng.random() < 0.2 else 0.2, 1.2, (nb, nc // 3))
+    return P.Batch(Q, b, A, beq, mu, lb, ub)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    # python tools/fuzz_parity.py <seconds> <seed> <case> [<case> ...]: only those cases of the seed's sequence are solved
+    # (the others are generated and dropped), and each is saved as gpurun_out/fuzz_case_<seed>_<case>.npz
+    replay = sorted(int(a) for a in sys.argv[3:])
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    cases = bad = notable = 0
+    worst = 0.0
+    t_print = time.time()
+    while time.time() < t_end:
+        cases += 1
+        r = rng.random()
+        if r < 0.35: dims = FUSED[int(rng.integers(len(FUSED)))]
+        elif r < 0.5: dims = COOP[int(rng.integers(len(COOP)))]
+        else: dims = random_shape(rng)
+        kernels = [CAPI.KERNEL_AUTO, CAPI.KERNEL_GENERIC]
+        if dims in FUSED: kernels += [CAPI.KERNEL_FUSED, CAPI.KERNEL_FUSED_SPLIT]
+        if dims in COOP: kernels += [CAPI.KERNEL_COOP]
+        kernel = kernels[int(rng.integers(len(kernels)))]
+        nb = int(rng.choice([1, 2, 3, 7, 17, 64, 65, 130, 200]))
+        if dims[0] > 100: nb = min(nb, 17)
+        singular = rng.random() < 0.08
+        opts = dict(max_iter=int(rng.choice([0, 1, 2, 5, 15, 40, 100, 300])), rho=float(10.0 ** rng.uniform(-6, 0)),
+                    eps_fcone=float(10.0 ** rng.uniform(-8, -2)), eps_bound=float(10.0 ** rng.uniform(-8, -2)))
+        B = random_batch(rng, dims, nb, singular)
+        tag = f"case {cases} dims {dims} kernel {kernel} batch {nb} opts {opts} singular {singular}"
+        if replay:
+            if cases > replay[-1]: break
+            if cases not in replay: continue
+        try:
+            s = CAPI.Solver(*dims, batch=nb); s.set_options(**opts); s.set_kernel(kernel)
+            s.solve_ok(*B.arrays())
+            z, d = s.solution()
+        except Exception as e:                               # noqa: BLE001
+            print("ERROR", tag, repr(e), flush=True); bad += 1; continue
+        it = np.array([x.n_iter for x in d]); fl = np.array([x.flags for x in d])
+        z_ref, it_ref, _, _ = O.solve_batch(dims, opts, *B.arrays(), nthreads=8)
+        if replay:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_case_{seed}_{cases}.npz"), dims=np.array(dims), kernel=kernel,
+                     max_iter=opts["max_iter"], rho=opts["rho"], eps_fcone=opts["eps_fcone"], eps_bound=opts["eps_bound"],
+                     z_gpu=z, it_gpu=it, flags=fl, z_oracle=z_ref, it_oracle=it_ref,
+                     **{k: v for k, v in zip(("Q", "b", "A", "b_eq", "mu", "lb", "ub"), B.arrays())})
+        err = np.max(np.abs(z - z_ref), axis=1) / (1.0 + np.max(np.abs(z_ref), axis=1))
+        dn = np.abs(it.astype(np.int64) - it_ref.astype(np.int64))
+        e, dm = float(np.nanmax(err)) if np.all(np.isfinite(z)) else float("inf"), int(dn.max())
+        tol = 1e-4 if singular else 1e-6
+        broken = (not np.isfinite(e)) or e > tol or (dm > 1 and not singular)
+        if broken and np.isfinite(e) and not singular:
+            # who is right?  The same algorithm in 80-bit arithmetic on the worst instance (tools/referee_longdouble.py):
+            # an ill-conditioned K_rho shows as BOTH sides being off by about as much -- not a defect of either
+            from tools import referee_longdouble as R
+            i = int(np.argmax(err))
+            zr, _ = R.solve(*dims, opts, *[x[i] for x in B.arrays()])
+            sc = 1 + float(np.max(np.abs(zr)))
+            eg = float(np.max(np.abs(z[i] - zr))) / sc; eo = float(np.max(np.abs(z_ref[i] - zr))) / sc
+            tag += f" | referee: gpu {eg:.1e} oracle {eo:.1e}"
+            if eg <= 10 * max(eo, 1e-12) and dm <= 1:
+                broken = False; tag += " (ill-conditioned input, both sides off alike)"
+        if broken: bad += 1
+        if broken or e > 1e-9 or dm > 0:
+            notable += 1
+            print("BROKEN" if broken else "note", tag, f"rel err {e:.2e} dn_iter {dm} flags {sorted(set(fl.tolist()))} "
+                  f"n_iter ref {sorted(set(it_ref.tolist()))[:6]}", flush=True)
+        worst = max(worst, e if np.isfinite(e) and not singular else 0.0)
+        # warm-started second solve of the same inputs, against the oracle's class (small batches)
+        if nb <= 3 and not singular and opts["max_iter"] > 0:
+            s.set_warm_start(True); s.solve_ok(*B.arrays()); z2, d2 = s.solution()
+            for i in range(nb):
+                o = O.OracleFCCQP(*dims); oo = O.FCCQPOptions()
+                oo.max_iter, oo.rho, oo.eps_fcone, oo.eps_bound = opts["max_iter"], opts["rho"], opts["eps_fcone"], opts["eps_bound"]
+                o.set_options(oo)
+                a = [x[i] for x in B.arrays()]
+                o.Solve(*a); o.set_warm_start(True); o.Solve(*a)
+                sol = o.GetSolution()
+                e2 = float(np.max(np.abs(z2[i] - sol.z)) / (1.0 + np.max(np.abs(sol.z))))
+                d2n = abs(int(d2[i].n_iter) - int(sol.details.n_iter))
+                if e2 > 1e-6 or d2n > 1:
+                    bad += 1
+                    print("BROKEN warm", tag, f"instance {i} rel err {e2:.2e} dn_iter {d2n}", flush=True)
+                worst = max(worst, e2)
+        s.close()
+        if time.time() - t_print > 50:
+            print(f"... {cases} cases, {bad} broken, worst rel err {worst:.2e}", flush=True); t_print = time.time()
+    print(f"fuzz: {cases} cases, {notable} notable, {bad} broken, worst rel err (non-singular) {worst:.2e}", flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,13 @@
+"""A bounded run of tools/fuzz_parity.py: random shapes (listed and unlisted, one to eight register slots), kernels,
+options, batch sizes and inputs, cold and warm, f64 and f32 storage, against the oracle; disagreements beyond the stated
+tolerance are refereed in 80-bit arithmetic (tools/referee_longdouble.py).  The long runs (75 000 cases per seed) are a
+tool; this keeps a fixed 1 500-case prefix of one seed in the suite.  Round 4: the tool found the generic kernel's
+four-wave race between the presolve's sweeps and the copy of rho G (tests/test_gpu_parity.py, shapes (89, 40), ...)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fixed_prefix_of_the_random_parity_run():
+    from tools import fuzz_parity
+    assert fuzz_parity.main(budget=240.0, seed=4, max_cases=1500) == 0

@@ -22,8 +22,12 @@ COOP = [(114, 60, 24, 66), (60, 38, 12, 38), (70, 20, 9, 40), (32, 14, 6, 20), (
 
 
 def random_shape(rng):
-    n = int(rng.integers(3, 90))
-    m = int(rng.integers(0, min(n, 50)))
+    if rng.random() < 0.2:                                   # three / four register slots, N up to 512
+        n = int(rng.integers(70, 260))
+        m = int(rng.integers(0, min(n, 512 - n, 140)))
+    else:
+        n = int(rng.integers(3, 90))
+        m = int(rng.integers(0, min(n, 50)))
     ncmax = min(n // 3, 8)
     k = int(rng.integers(0, ncmax + 1))
     nc = 3 * k
@@ -62,18 +66,16 @@ def random_batch(rng, dims, nb, singular):
     return P.Batch(Q, b, A, beq, mu, lb, ub)
 
 
-def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def main(budget=120.0, seed=1, replay=(), max_cases=None):
     # python tools/fuzz_parity.py <seconds> <seed> <case> [<case> ...]: only those cases of the seed's sequence are solved
     # (the others are generated and dropped), and each is saved as gpurun_out/fuzz_case_<seed>_<case>.npz
-    replay = sorted(int(a) for a in sys.argv[3:])
+    replay = sorted(int(a) for a in replay)
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     cases = bad = notable = 0
     worst = 0.0
     t_print = time.time()
-    while time.time() < t_end:
+    while time.time() < t_end and (max_cases is None or cases < max_cases):
         cases += 1
         r = rng.random()
         if r < 0.35: dims = FUSED[int(rng.integers(len(FUSED)))]
@@ -85,17 +87,21 @@ def main():
         kernel = kernels[int(rng.integers(len(kernels)))]
         nb = int(rng.choice([1, 2, 3, 7, 17, 64, 65, 130, 200]))
         if dims[0] > 100: nb = min(nb, 17)
+        if dims[0] + dims[1] > 256: nb = min(nb, 3)
+        f32 = rng.random() < 0.1                             # fp32-storage entry point: the oracle gets the rounded inputs
         singular = rng.random() < 0.08
         opts = dict(max_iter=int(rng.choice([0, 1, 2, 5, 15, 40, 100, 300])), rho=float(10.0 ** rng.uniform(-6, 0)),
                     eps_fcone=float(10.0 ** rng.uniform(-8, -2)), eps_bound=float(10.0 ** rng.uniform(-8, -2)))
         B = random_batch(rng, dims, nb, singular)
-        tag = f"case {cases} dims {dims} kernel {kernel} batch {nb} opts {opts} singular {singular}"
+        if f32:
+            B = P.Batch(*(np.asarray(np.asarray(a, dtype=np.float32), dtype=np.float64) for a in B.arrays()))
+        tag = f"case {cases} dims {dims} kernel {kernel} batch {nb} opts {opts} singular {singular}" + (" f32" if f32 else "")
         if replay:
             if cases > replay[-1]: break
             if cases not in replay: continue
         try:
             s = CAPI.Solver(*dims, batch=nb); s.set_options(**opts); s.set_kernel(kernel)
-            s.solve_ok(*B.arrays())
+            (s.solve_f32_ok if f32 else s.solve_ok)(*B.arrays())
             z, d = s.solution()
         except Exception as e:                               # noqa: BLE001
             print("ERROR", tag, repr(e), flush=True); bad += 1; continue
@@ -131,13 +137,16 @@ def main():
         worst = max(worst, e if np.isfinite(e) and not singular else 0.0)
         # warm-started second solve of the same inputs, against the oracle's class (small batches)
         if nb <= 3 and not singular and opts["max_iter"] > 0:
-            s.set_warm_start(True); s.solve_ok(*B.arrays()); z2, d2 = s.solution()
+            arr2 = list(B.arrays())
+            arr2[1] = arr2[1] + 0.05 * rng.standard_normal(arr2[1].shape)      # the next QP of a sequence: b moves a little
+            if f32: arr2[1] = np.asarray(np.asarray(arr2[1], dtype=np.float32), dtype=np.float64)
+            s.set_warm_start(True); (s.solve_f32_ok if f32 else s.solve_ok)(*arr2); z2, d2 = s.solution()
             for i in range(nb):
                 o = O.OracleFCCQP(*dims); oo = O.FCCQPOptions()
                 oo.max_iter, oo.rho, oo.eps_fcone, oo.eps_bound = opts["max_iter"], opts["rho"], opts["eps_fcone"], opts["eps_bound"]
                 o.set_options(oo)
                 a = [x[i] for x in B.arrays()]
-                o.Solve(*a); o.set_warm_start(True); o.Solve(*a)
+                o.Solve(*a); o.set_warm_start(True); o.Solve(*[x[i] for x in arr2])
                 sol = o.GetSolution()
                 e2 = float(np.max(np.abs(z2[i] - sol.z)) / (1.0 + np.max(np.abs(sol.z))))
                 d2n = abs(int(d2[i].n_iter) - int(sol.details.n_iter))
@@ -153,4 +162,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, sys.argv[3:]))

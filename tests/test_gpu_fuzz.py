@@ -11,3 +11,11 @@ pytestmark = pytest.mark.gpu
 def test_fixed_prefix_of_the_random_parity_run():
     from tools import fuzz_parity
     assert fuzz_parity.main(budget=240.0, seed=4, max_cases=1500) == 0
+
+
+def test_fixed_prefix_of_the_random_call_sequences():
+    """tools/fuzz_api.py: chains of option / warm-start / kernel changes, state transplants and solves through every
+    entry point (host, host-async, device pointers on three streams, f32), fetched by GetSolution, by the asynchronous
+    copy or not at all, mirrored by one oracle object per instance (50 000 chains / 236 000 solves clean in round 4)."""
+    from tools import fuzz_api
+    assert fuzz_api.main(budget=240.0, seed=5, max_chains=400) == 0

@@ -117,7 +117,7 @@ def build_all(force: bool = False) -> None:
 
 def add_shape(kind: str, dims) -> bool:
     """Appends a shape to csrc/fused_shapes.def (kind "fused": num_vars <= 63, one wavefront per QP) or
-    csrc/coop_shapes.def (kind "coop": num_vars <= 128, `waves` wavefronts per QP) unless it is listed already;
+    csrc/coop_shapes.def (kind "coop": num_vars <= ~118, `waves` wavefronts per QP) unless it is listed already;
     the next build compiles the specialised kernel for it (static_asserts in the kernels' Shape structs say so if the
     shape does not qualify).  Every other shape runs on the generic kernel, several times slower."""
     dims = tuple(int(d) for d in dims)

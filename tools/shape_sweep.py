@@ -1,7 +1,8 @@
 """Parity of fused kernels compiled for shapes beyond the shipped list (the claim of fused_shapes.def: "add your robot's
 shape"): run with FCCQP_LIB_PATH pointing at a library built with the extra shapes in fused_shapes.def
 (tools/variant_lib.sh), one-launch and two-launch form, cold and warm, f64 and f32 storage, against the oracle.
-    FCCQP_LIB_PATH=tools/ab/libfccqp_hip_sweep.so python tools/shape_sweep.py "7 2 3 4" "16 0 3 0" ..."""
+    FCCQP_LIB_PATH=tools/ab/libfccqp_hip_sweep.so python tools/shape_sweep.py "7 2 3 4" "16 0 3 0" ...
+SWEEP_KERNEL=coop: the cooperative kernel instead (shapes added to coop_shapes.def)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +24,7 @@ for spec in sys.argv[1:]:
         B = random_batch(rng, dims, nb, singular=(trial == 5))
         if f32: B = P.Batch(*(np.asarray(np.asarray(a, dtype=np.float32), dtype=np.float64) for a in B.arrays()))
         z_ref, it_ref, _, _ = O.solve_batch(dims, opts, *B.arrays(), nthreads=8)
-        for kernel in (CAPI.KERNEL_FUSED, CAPI.KERNEL_FUSED_SPLIT):
+        for kernel in ((CAPI.KERNEL_COOP,) if os.environ.get("SWEEP_KERNEL") == "coop" else (CAPI.KERNEL_FUSED, CAPI.KERNEL_FUSED_SPLIT)):
             s = CAPI.Solver(*dims, batch=nb); s.set_options(**opts); s.set_kernel(kernel)
             (s.solve_f32_ok if f32 else s.solve_ok)(*B.arrays())
             assert s.kernel() == kernel

@@ -48,9 +48,14 @@ enum {
   FCCQP_ERR_ALLOC = 5,
   FCCQP_ERR_FRICTION_COEFFS = 6, /* fewer than nc/3 coefficients: the reference throws
                                     std::out_of_range from .at() (constraint_utils.cpp:32,55)   */
-  FCCQP_ERR_NOT_SOLVED = 7,      /* get_solution before any solve                               */
-  FCCQP_ERR_UNSUPPORTED = 8      /* shape too large for the device workspace                    */
+  FCCQP_ERR_NOT_SOLVED = 7,      /* get_solution before any solve, or after a solve that failed */
+  FCCQP_ERR_UNSUPPORTED = 8      /* shape too large for the device workspace, or no kernel of
+                                    the requested kind (fccqp_set_kernel) for this shape         */
 };
+/* A solve entry point that returns an error leaves the handle as before its first solve: nothing of that solve is
+ * still running or copying when the call returns (the caller's arrays are free), fccqp_get_solution answers
+ * FCCQP_ERR_NOT_SOLVED rather than the previous solve's z, and the handle can solve again.  The warm-start state is
+ * whatever the kernels that did run left: start cold after an error. */
 
 /* reference: enum FCCQPSolveStatus, src/fcc_qp.hpp:14-17 */
 enum { FCCQP_STATUS_SUCCESS = 0, FCCQP_STATUS_MAX_ITERATIONS = 1 };

@@ -22,7 +22,7 @@ COOP = [(114, 60, 24, 66), (60, 38, 12, 38), (70, 20, 9, 40), (32, 14, 6, 20), (
 
 
 def random_shape(rng):
-    if rng.random() < 0.2:                                   # three / four register slots, N up to 512
+    if rng.random() < (0.9 if os.environ.get("FUZZ_BIG") else 0.2):    # three / four / eight register slots, N up to 512
         n = int(rng.integers(70, 260))
         m = int(rng.integers(0, min(n, 512 - n, 140)))
     else:
@@ -85,6 +85,7 @@ def main(budget=120.0, seed=1, replay=(), max_cases=None):
             if cases not in replay: continue
         rng = np.random.default_rng([seed, cases])              # every case has a generator of its own: replayable alone
         r = rng.random()
+        if os.environ.get("FUZZ_BIG"): r = 0.5 + 0.5 * r       # (FUZZ_BIG=1: random shapes only, nine in ten of them large)
         if r < 0.35: dims = FUSED[int(rng.integers(len(FUSED)))]
         elif r < 0.5: dims = COOP[int(rng.integers(len(COOP)))]
         else: dims = random_shape(rng)

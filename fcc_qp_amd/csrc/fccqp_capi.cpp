@@ -147,7 +147,13 @@ template <class T>
 hipError_t dmalloc(T **p, size_t count) {
   const size_t bytes = (count ? count : 1) * sizeof(T);
   hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
-  if (e == hipSuccess && poison_allocations()) e = hipMemset(*p, 0xFF, bytes);
+  if (e == hipSuccess && poison_allocations()) {
+    // (hipMemset on device memory returns before the fill has run, and the solver's own stream is a non-blocking one
+    // that does not wait for the null stream: without the wait the fill can land ON TOP of the first copy into the
+    // block -- the randomised API run with poisoning showed exactly that, NaN inputs in one solve in 5 000)
+    e = hipMemset(*p, 0xFF, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  }
   return e;
 }
 
@@ -518,6 +524,9 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
     HIP_TRY(s, hipMemset(s->dfb_list, 0, sizeof(int) * (B + 2)));
     HIP_TRY(s, dmalloc(&s->dfb_count, 2));
     HIP_TRY(s, hipMemset(s->dfb_count, 0, 2 * sizeof(int)));
+    // the fills above are enqueued on the null stream and need not have run when hipMemset returns; solves run on
+    // non-blocking streams, which do not wait for it: make the zero state a fact before the handle is handed out
+    HIP_TRY(s, hipStreamSynchronize(nullptr));
 #ifdef FCCQP_TICKET_DISPATCH
     HIP_TRY(s, dmalloc(&s->dticket, 1));
     HIP_TRY(s, hipMemset(s->dticket, 0, sizeof(unsigned)));
@@ -1045,6 +1054,7 @@ int fccqp_phase_seconds(fccqp_solver *s, double out[8]) {
     HIP_TRY(s, wait_last(s));
     HIP_TRY(s, dmalloc(&s->dphase, 8 * B));
     HIP_TRY(s, hipMemset(s->dphase, 0, sizeof(long long) * 8 * B));
+    HIP_TRY(s, hipStreamSynchronize(nullptr));       // (see fccqp_create: the fill runs on the null stream)
     return FCCQP_OK;
   }
   if (!s->solved) return FCCQP_OK;

@@ -107,6 +107,7 @@ def main(budget=120.0, seed=1, replay=(), max_cases=None):
         tag = f"case {cases} dims {dims} kernel {kernel} batch {nb} opts {opts} singular {singular}" + (" f32" if f32 else "")
         try:
             s = CAPI.Solver(*dims, batch=nb); s.set_options(**opts); s.set_kernel(kernel)
+            if os.environ.get("FUZZ_SELF_CHECK"): s.set_self_check(True)     # the equality-residual check behind every solve
             (s.solve_f32_ok if f32 else s.solve_ok)(*B.arrays())
             z, d = s.solution()
         except Exception as e:                               # noqa: BLE001
@@ -140,6 +141,8 @@ def main(budget=120.0, seed=1, replay=(), max_cases=None):
             # benign: both sides off alike, or off by no more than the conditioning explains (~50 eps cond)
             if dm <= 1 and (eg <= 10 * max(eo, 1e-12) or eg <= 1e-14 * cond):
                 broken = False; tag += " (ill-conditioned input)"
+        if os.environ.get("FUZZ_SELF_CHECK") and not singular and np.any(fl & 32):
+            broken = True; tag += " | FLAG_EQ_RESIDUAL raised on a sound solve"
         if broken: bad += 1
         if broken or e > 1e-9 or dm > 0:
             notable += 1

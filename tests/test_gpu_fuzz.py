@@ -19,3 +19,11 @@ def test_fixed_prefix_of_the_random_call_sequences():
     copy or not at all, mirrored by one oracle object per instance (50 000 chains / 236 000 solves clean in round 4)."""
     from tools import fuzz_api
     assert fuzz_api.main(budget=240.0, seed=5, max_chains=400) == 0
+
+
+def test_fixed_prefix_of_the_random_python_surface_run():
+    """tools/fuzz_python.py: the reference's FCCQP class (and FCCQPBatch) fed numpy arrays in every layout the
+    reference's Eigen::Ref casters accept -- C / Fortran order, strided and reversed views, float32, (n,1) / (1,n)
+    vectors, lists, keyword arguments (50 000 cases clean in round 4)."""
+    from tools import fuzz_python
+    assert fuzz_python.main(budget=240.0, seed=2, max_cases=300) == 0

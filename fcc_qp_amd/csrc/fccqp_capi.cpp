@@ -630,6 +630,15 @@ int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {
   *kernel_in_use = k;
   return FCCQP_OK;
 }
+int fccqp_kernel_for_shape(int num_vars, int num_equality_constraints, int nc, int lambda_c_start) {
+  if (num_vars < 0 || num_equality_constraints < 0 || nc < 0 || nc % 3 != 0 || lambda_c_start < 0 ||
+      lambda_c_start + nc > num_vars)
+    return -FCCQP_ERR_SHAPE;
+  if (num_vars + num_equality_constraints > fccqp::kGenericMaxN) return -FCCQP_ERR_UNSUPPORTED;
+  if (fccqp::fused_supported(num_vars, num_equality_constraints, nc, lambda_c_start)) return FCCQP_KERNEL_FUSED;
+  if (fccqp::coop_supported(num_vars, num_equality_constraints, nc, lambda_c_start)) return FCCQP_KERNEL_COOP;
+  return FCCQP_KERNEL_GENERIC;
+}
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc, int *lambda_c_start,
                     int *batch, int *device) {
   if (!s) return FCCQP_ERR_INVALID_ARG;

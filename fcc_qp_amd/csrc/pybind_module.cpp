@@ -343,6 +343,16 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def("LastKernelMilliseconds", &fcc_qp::FCCQPSharded::LastKernelMilliseconds);
 
   m.def("device_count", &fccqp_device_count);
+  m.def("kernel_for_shape",
+        [](int num_vars, int num_equality_constraints, int nc, int lambda_c_start) {
+          const int k = fccqp_kernel_for_shape(num_vars, num_equality_constraints, nc, lambda_c_start);
+          if (k < 0) throw py::value_error(std::string("kernel_for_shape: ") + fccqp_strerror(-k));
+          return k;
+        },
+        py::arg("num_vars"), py::arg("num_equality_constraints"), py::arg("nc"), py::arg("lambda_c_start"),
+        "Which kernel KERNEL_AUTO takes for an FCCQP(num_vars, num_equality_constraints, nc, lambda_c_start) in this build: "
+        "KERNEL_FUSED / KERNEL_COOP for a shape compiled in (fused_shapes.def / coop_shapes.def), KERNEL_GENERIC otherwise "
+        "(several times slower; `python fcc_qp_amd/build.py --add-fused-shape n m nc s` adds it).  Needs no GPU.");
   m.attr("KERNEL_AUTO") = (int)FCCQP_KERNEL_AUTO;
   m.attr("KERNEL_GENERIC") = (int)FCCQP_KERNEL_GENERIC;
   m.attr("KERNEL_FUSED") = (int)FCCQP_KERNEL_FUSED;

@@ -162,6 +162,12 @@ int fccqp_set_kernel_timing(fccqp_solver *s, int enabled);
  * reference has no counterpart: it reports nothing about the quality of a solve beyond n_iter. */
 int fccqp_set_self_check(fccqp_solver *s, int enabled);
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use);
+/* Which kernel FCCQP_KERNEL_AUTO takes for a shape in THIS build of the library (no handle, no device needed):
+ * FCCQP_KERNEL_FUSED or FCCQP_KERNEL_COOP for the constructor arguments listed in fused_shapes.def / coop_shapes.def
+ * when the library was built, FCCQP_KERNEL_GENERIC for every other valid shape (several times slower: add the shape
+ * and rebuild), a negative status code (-FCCQP_ERR_SHAPE, -FCCQP_ERR_UNSUPPORTED) for arguments
+ * fccqp_create would refuse. */
+int fccqp_kernel_for_shape(int num_vars, int num_equality_constraints, int nc, int lambda_c_start);
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
                     int *lambda_c_start, int *batch, int *device);
 

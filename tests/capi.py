@@ -65,6 +65,8 @@ def lib():
             L.fccqp_set_self_check.argtypes = [C.c_void_p, C.c_int]
             L.fccqp_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.fccqp_get_kernel.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        if hasattr(L, "fccqp_kernel_for_shape"):
+            L.fccqp_kernel_for_shape.argtypes = [C.c_int] * 4
         L.fccqp_solve.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.fccqp_solve_device.argtypes = [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p]
         L.fccqp_solve_f32.argtypes = [C.c_void_p, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp, _fp]

@@ -52,6 +52,7 @@ int fccqp_set_presolve_fallback(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_set_kernel_timing(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_set_self_check(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_get_kernel(const fccqp_solver *s, int *k) { *k = s->kernel; return FCCQP_OK; }
+int fccqp_kernel_for_shape(int, int, int, int) { return FCCQP_KERNEL_GENERIC; }
 int fccqp_get_shape(const fccqp_solver *s, int *n, int *m, int *nc, int *st, int *b, int *d) {
   if (n) *n = s->n; if (m) *m = s->m; if (nc) *nc = s->nc; if (st) *st = s->s; if (b) *b = s->batch; if (d) *d = s->device;
   return FCCQP_OK;

@@ -93,3 +93,20 @@ def test_python_surface_names_match_reference_binding():
             F.FCCQP(60, 38, 12, 38)
         with pytest.raises(ValueError):
             F.FCCQP(60, 38, 13, 38)
+
+
+def test_kernel_for_shape_needs_no_device():
+    """fccqp_kernel_for_shape: what FCCQP_KERNEL_AUTO takes for a shape in this build -- the shapes of fused_shapes.def /
+    coop_shapes.def get their kernels, any other valid shape the generic one, invalid sizes a negative status."""
+    L = C.lib()
+    assert L.fccqp_kernel_for_shape(60, 38, 12, 38) == C.KERNEL_FUSED          # reference harness shape
+    assert L.fccqp_kernel_for_shape(114, 60, 24, 66) == C.KERNEL_COOP          # large shape
+    assert L.fccqp_kernel_for_shape(61, 38, 12, 38) == C.KERNEL_GENERIC
+    assert L.fccqp_kernel_for_shape(20, 5, 0, 0) == C.KERNEL_GENERIC
+    assert L.fccqp_kernel_for_shape(10, 4, 4, 0) == -C.ERR_SHAPE               # nc % 3
+    assert L.fccqp_kernel_for_shape(10, 4, 6, 6) == -C.ERR_SHAPE               # lambda_c_start + nc > num_vars
+    assert L.fccqp_kernel_for_shape(400, 113, 12, 100) == -C.ERR_UNSUPPORTED   # n + m > 512
+    import fcc_qp_amd as F
+    assert F.kernel_for_shape(60, 38, 12, 38) == F.KERNEL_FUSED and F.kernel_for_shape(7, 2, 3, 4) == F.KERNEL_GENERIC
+    with pytest.raises(ValueError):
+        F.kernel_for_shape(10, 4, 4, 0)

@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 BATCH_PER_GPU = 4096
+SETTLE = True           # untimed steps until the clocks are steady, in front of every timed region (--no-settle: off)
 
 
 def parse_args():
@@ -67,6 +68,8 @@ def parse_args():
     ap.add_argument("--single-input-set", action="store_true",
                     help="re-solve ONE resident batch every step (rounds 1-2 did; its inputs then partly sit in the "
                          "Infinity Cache); default: alternate between two resident copies")
+    ap.add_argument("--no-settle", action="store_true",
+                    help="skip the untimed clock-settling steps in front of the W warm-up steps (see _settle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -190,6 +193,34 @@ def cpu_baseline(shape, options, batch_obj, log):
     }
 
 
+def _settle(torch, step, enabled=True, block=10, tol=0.005, max_blocks=40):
+    """Untimed steps until the GPU has reached its steady clocks: a card that has idled for the seconds the CPU parts of
+    this script take (problem generation, the oracle) starts ~6 % slow and needs ~25 launches (7 ms) to ramp up -- measured:
+    steps 6-25 after an idle phase 0.282 ms, steps 51-70 0.264 ms, same kernel, same inputs.  Blocks of `block` steps,
+    each between one event pair; done when two successive blocks agree with their predecessor to `tol`, or after
+    `max_blocks`.  Returns the number of steps run (reported as `settle_steps`).  Not part of the contract's W warm-up
+    steps, which follow; nothing here is timed into `value`."""
+    _settle.trace = []                   # ms per step of every block of the last call (reported for the headline)
+    if not enabled:
+        return 0
+    prev, stable, n = None, 0, 0
+    for _ in range(max_blocks):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(block):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        n += block
+        ms = e0.elapsed_time(e1)
+        _settle.trace.append(ms / block)
+        stable = stable + 1 if (prev is not None and abs(ms - prev) <= tol * ms) else 0
+        prev = ms
+        if stable >= 2:
+            break
+    return n
+
+
 def _timed_steps(torch, step, steps, warmup):
     """W untimed + K timed steps of `step` on torch's current stream, back to back, ONE HIP event pair around the
     K steps (an event between two steps makes the second wait for the stream to drain: ~5 us of stream time each,
@@ -254,6 +285,7 @@ def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup
         step(); torch.cuda.synchronize()
         cold = solver.GetSolution()
         par = _parity(O, shape, options, batch, cold.z, cold.n_iter, parity_k)
+        _settle(torch, step, SETTLE)          # (cold solves: a warm chain would converge further with every step)
         if warm:
             solver.set_warm_start(True)
         wall, kms = _timed_steps(torch, step, steps, warmup)
@@ -324,6 +356,7 @@ def two_streams(F, P, torch, dev, dev_index, log, steps=20, warmup=4):
         for i in range(k):
             F.solve_tensors(solvers[i & 1], *sets[i & 1], stream=streams[i & 1])
 
+    _settle(torch, lambda: run(2), SETTLE, block=5)
     run(warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -357,6 +390,7 @@ def batch_sweep(F, P, torch, dev, dev_index, log):
         o.max_iter, o.rho, o.eps_fcone, o.eps_bound = (P.HARNESS_OPTIONS[k] for k in ("max_iter", "rho", "eps_fcone", "eps_bound"))
         solver.set_options(o)
         steps = 20 if nb <= 8192 else 5
+        _settle(torch, lambda: F.solve_tensors(solver, *tens), SETTLE, block=(10 if nb <= 8192 else 2))
         wall, kms = _timed_steps(torch, lambda: F.solve_tensors(solver, *tens), steps, 2)
         sol = solver.GetSolution()
         z = np.asarray(sol.z)
@@ -481,6 +515,8 @@ def end_to_end(P, O, dev_index, log, handles=3, rounds=12, f32=False):
 
 def main():
     args = parse_args()
+    global SETTLE
+    SETTLE = not args.no_settle
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -565,6 +601,10 @@ def main():
         log(f"[bench] parity vs oracle on {k} instances: {parity}")
 
     # ---- timed region ------------------------------------------------------------------------------
+    settle_steps = _settle(torch, step, SETTLE)     # clocks up after the CPU phases above (untimed, cold solves)
+    settle_trace = [round(v, 4) for v in _settle.trace]
+    if settle_trace:
+        log(f"[bench] settle: {settle_steps} untimed steps, ms per step by block of 10: {settle_trace}")
     if args.warm:
         solver.set_warm_start(True)     # state (x, mu) stays resident; the presolve is skipped (fcc_qp.cpp:159)
     for _ in range(args.warmup):
@@ -628,7 +668,8 @@ def main():
                 "collective_bytes_per_run": 16 if world > 1 else 0,
                 "kernel": KERNEL_NAMES[solver.kernel_in_use()], "input_storage": args.inputs,
                 "n_iter_mean": float(n_iter.mean()), "n_iter_at_max_frac": float(np.mean(n_iter == options["max_iter"])),
-                "resident_input_sets": len(sets),
+                "resident_input_sets": len(sets), "settle_steps": settle_steps,
+                "settle_ms_per_step_first_last": ([settle_trace[0], settle_trace[-1]] if settle_trace else None),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -46,6 +46,25 @@ for k in fetch:
         "correction": "2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B for 16 B/lane streams) + WRITE_SIZE",
         "trace_average_ns": avg_ns, "trace_max_ns": max_ns,
     }
+# The rocprofv3 average above runs over EVERY launch of the command, also the untimed ones in front of the timed region
+# (parity solve, clock-settling steps, warm-up: bench.py _settle) during which a card coming out of idle is still
+# ramping its clocks.  The launches of the timed region itself, from the raw trace: the main kernel's launches in
+# start order end with [K timed][min(K, 20) isolated] (bench.py main()).
+try:
+    bench = json.loads(open(os.path.join(src, "bench_under_trace.json")).read().strip().splitlines()[-1])
+    K = int(bench["steps"]); iso = min(K, 20)
+    rows = [r for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv")))]
+    for k in summary["kernels"]:
+        mine = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if r["Kernel_Name"] == k)
+        big = [e - b for b, e in mine if (e - b) >= 0.1 * max(e2 - b2 for b2, e2 in mine)]
+        if len(big) >= K + iso:
+            timed = big[-(K + iso):-iso]
+            summary["kernels"][k]["trace_timed_region_average_ns"] = sum(timed) / len(timed)
+            summary["kernels"][k]["trace_timed_region_launches"] = len(timed)
+    summary["bench_under_trace"] = {"kernel_ms_mean": bench["roofline"]["kernel_ms_mean"], "steps": K,
+                                    "settle_steps": bench["config"].get("settle_steps")}
+except Exception as exc:          # (older traces without the raw csv)
+    summary["trace_timed_region_error"] = repr(exc)
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 main = max(summary["kernels"].items(), key=lambda kv: kv[1]["hbm_bytes_per_launch_corrected"])
 kernel_id = 2 if "fused" in main[0] else (4 if "coop" in main[0] else 1)

@@ -99,6 +99,7 @@ def main(budget=120.0, seed=1, replay=(), max_cases=None):
         if dims[0] + dims[1] > 256: nb = min(nb, 3)
         f32 = rng.random() < 0.1                             # fp32-storage entry point: the oracle gets the rounded inputs
         singular = rng.random() < 0.08
+        if dims[1] >= dims[0] - 1: singular = False         # (a dead variable under n - 1 or n equality rows makes A_eq rank-deficient)
         opts = dict(max_iter=int(rng.choice([0, 1, 2, 5, 15, 40, 100, 300])), rho=float(10.0 ** rng.uniform(-6, 0)),
                     eps_fcone=float(10.0 ** rng.uniform(-8, -2)), eps_bound=float(10.0 ** rng.uniform(-8, -2)))
         B = random_batch(rng, dims, nb, singular)

@@ -11,6 +11,19 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     return (total * rank) // world, (total * (rank + 1)) // world
 
 
+#: the global batches bench.py times split over the ranks beside its weak-scaling headline (label, instances):
+#: the metric's batch (4096 / G per GPU) and BASELINE configs[4] (65536: 8192 per GPU on 8 GPUs)
+SHARDED_RECORDS = (("strong_batch4096", 4096), ("config4_65536", 65536))
+
+
+def shard_plan(total: int, world: int, rank: int, base: int = 1000, tile_above: int = 2048, tile_from: int = 256):
+    """What rank `rank` solves of ONE global batch of `total` instances (instance i: generator seed base + i):
+    (lo, hi, seed0, distinct) -- its contiguous range, the seed of its first instance, and how many distinct
+    instances it generates (None: all of them; shards above `tile_above` are tiled from their first `tile_from`)."""
+    lo, hi = shard_bounds(total, world, rank)
+    return lo, hi, base + lo, (None if hi - lo <= tile_above else tile_from)
+
+
 def rank_seed0(rank: int, per_rank: int, base: int = 1000) -> int:
     """First generator seed of a rank under weak scaling (instance i of the global batch: base + i)."""
     return base + rank * per_rank

@@ -45,6 +45,17 @@ def test_settle_is_bounded_and_can_be_switched_off():
     assert bench._settle(t, step, False) == 0 and bench._settle.trace == []
 
 
+def test_settle_on_the_host_clock_for_steps_on_side_streams(monkeypatch):
+    """two_streams launches on streams of its own: an event pair on the current stream brackets nothing there, so the
+    settling loop times its blocks on the host clock instead."""
+    t = _FakeTorch()
+    times = iter([0.30] * 5 + [0.28] * 5 + [0.265] * 1000)
+    def step(): t.now += next(times)
+    monkeypatch.setattr(bench.time, "perf_counter", lambda: t.now * 1e-3)
+    n = bench._settle(t, step, True, block=5, host_clock=True)
+    assert n == 25 and abs(bench._settle.trace[-1] - 0.265) < 1e-9
+
+
 def test_mfma_count_of_the_walking_shape():
     f, g, w = bench.fused_mfma_count(60, 38)
     assert (f, g, w) == (456, 196, 64)                           # 716 in the shipped code object (tests/test_code_objects.py)

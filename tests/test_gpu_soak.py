@@ -4,8 +4,8 @@ on three streams; every repetition must reproduce the first BIT FOR BIT (z, n_it
 The fused kernel carries hand-placed wait states that no compiler pass checks (tests/test_code_objects.py
 checks them statically), and this code base has seen one timing-dependent wrong-answer bug it could not
 explain (DESIGN.md section 7, N > 256): a kernel whose result depends on what else the chip is doing shows
-up here as a repetition that differs.  Three kernels are covered: the whole-solve fused kernel, its
-two-launch form and the generic kernel.  Reference work: one FCCQP::Solve per instance,
+up here as a repetition that differs.  All four kernel families are covered: the whole-solve fused kernel, its
+two-launch form, the generic kernel and (large shape, below) the cooperative kernel.  Reference work: one FCCQP::Solve per instance,
 /root/reference/src/fcc_qp.cpp:114-191 (deterministic by construction)."""
 import numpy as np
 import pytest
@@ -63,3 +63,82 @@ def test_two_hundred_repetitions_on_three_concurrent_handles(kernels):
             assert np.max(np.abs(zh - z0)) <= 1e-9 * (1 + np.max(np.abs(z0)))
     it = first[0]["n_iter"].cpu().numpy()
     assert (it == 100).sum() > 100 and (it < 5).sum() > 100          # the mix is a mix
+
+
+@pytest.mark.parametrize("nb,reps", [(16, 150), (1024, 40)])
+def test_cooperative_kernel_repetitions_on_three_concurrent_handles(nb, reps):
+    """The same for the cooperative kernel (eight waves per QP, workgroup barriers, LDS hand-offs between waves) on the
+    large shape, FCCQP(114, 60, 24, 66): handles ("coop", "coop", "generic") on three streams through the tensor entry
+    point, every repetition bit-identical to the first; batch 16 is the size of the one solve of round 4 that ended in
+    an unexplained abort (tests/conftest.py), batch 1024 fills the chip four times over."""
+    import torch
+    import fcc_qp_amd as F
+    from fcc_qp_amd import problems as P
+
+    kernels = ("coop", "coop", "generic")
+    kmap = {"coop": F.KERNEL_COOP, "generic": F.KERNEL_GENERIC}
+    dev = torch.device("cuda", 0)
+    base = P.workload("W-mix", nb, P.LARGE, distinct=16)
+    handles = []
+    for k, name in enumerate(kernels):
+        solver = F.FCCQPBatch(*P.LARGE.ctor_args, nb, 0)
+        o = F.FCCQPOptions()
+        o.max_iter, o.rho, o.eps_fcone, o.eps_bound = (P.HARNESS_OPTIONS[x] for x in ("max_iter", "rho", "eps_fcone", "eps_bound"))
+        solver.set_options(o)
+        solver.set_kernel(kmap[name])
+        tens = [torch.from_numpy(np.ascontiguousarray(np.roll(a, 3 * k, axis=0))).to(dev) for a in base.arrays()]
+        handles.append((solver, tens, torch.cuda.Stream(device=dev)))
+    torch.cuda.synchronize()
+    first, bad = [], []
+    for solver, tens, st in handles:
+        with torch.cuda.stream(st):
+            F.solve_tensors(solver, *tens, stream=st)
+            r = F.result_tensors(solver)
+            first.append({k: v.clone() for k, v in r.items()})
+            bad.append(torch.zeros((), dtype=torch.int64, device=dev))
+    for _ in range(reps):
+        for h, (solver, tens, st) in enumerate(handles):
+            with torch.cuda.stream(st):
+                F.solve_tensors(solver, *tens, stream=st)
+                r = F.result_tensors(solver)
+                for key, ref in first[h].items():
+                    a = r[key].view(torch.int64) if r[key].dtype == torch.float64 else r[key]
+                    b = ref.view(torch.int64) if ref.dtype == torch.float64 else ref
+                    bad[h] += (a != b).sum()
+    torch.cuda.synchronize()
+    assert [int(b.item()) for b in bad] == [0, 0, 0], f"repetitions differed: {[int(b.item()) for b in bad]} words"
+    assert [s.kernel_in_use() for s, _, _ in handles] == [F.KERNEL_COOP, F.KERNEL_COOP, F.KERNEL_GENERIC]
+    z0 = first[0]["z"].cpu().numpy()
+    z1 = np.roll(first[1]["z"].cpu().numpy(), -3, axis=0)
+    z2 = np.roll(first[2]["z"].cpu().numpy(), -6, axis=0)
+    assert np.array_equal(z1, z0)                                     # same kernel, other order, other stream
+    assert np.max(np.abs(z2 - z0)) <= 1e-9 * (1 + np.max(np.abs(z0)))
+    it = first[0]["n_iter"].cpu().numpy()
+    assert (it == 100).any() and (it < 100).any()
+
+
+@pytest.mark.parametrize("nb", [16, 1024])
+def test_cooperative_kernel_host_pointer_solves_on_fresh_handles(nb):
+    """Host-pointer solves (fccqp_solve: seven copies out of pageable memory, the kernel, a blocking wait) of the large
+    shape on the cooperative kernel, a fresh handle every seven solves, results compared bit for bit with the first solve
+    -- tools/stress_large_host.py (the path of round 4's one unexplained abort) as a bounded part of the suite."""
+    from fcc_qp_amd import problems as P
+    from tests import capi as CAPI
+
+    total = 420 if nb == 16 else 42
+    B = P.workload("W-mix", nb, P.LARGE, distinct=16)
+    ref, done = None, 0
+    while done < total:
+        s = CAPI.Solver(*P.LARGE.ctor_args, batch=nb)
+        s.set_options(**P.HARNESS_OPTIONS)
+        for _ in range(7):
+            s.set_warm_start(False)
+            s.solve_ok(*B.arrays())
+            z, d = s.solution()
+            done += 1
+            it = [x.n_iter for x in d]
+            if ref is None:
+                ref = (z.copy(), it)
+                assert s.kernel() == CAPI.KERNEL_COOP
+            assert np.array_equal(z, ref[0]) and it == ref[1], f"solve {done} differs from the first"
+        s.close()

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "fccqp_device.h"
+#include "fccqp_jit.h"
 
 struct fccqp_solver {
   int n = 0, m = 0, nc = 0, s = 0, batch = 0, device = 0;
@@ -100,6 +101,12 @@ struct fccqp_solver {
   // ticket the next launch starts at
   unsigned *dticket = nullptr;
   unsigned ticket_base = 0;
+  // run-time compiled specialised kernel (fccqp_jit.cpp) for a shape that is not compiled in: jit_kind is
+  // FCCQP_KERNEL_FUSED / FCCQP_KERNEL_COOP once fccqp_create has one (0: none); the float-storage instantiation is
+  // compiled on the first fp32-storage solve
+  int jit_kind = 0;
+  fccqp::jit::Kernel jit_f64{}, jit_f32{};
+  bool jit_f32_tried = false, jit_f32_ok = false;
   std::string err;
 };
 
@@ -244,9 +251,25 @@ int enqueue_impl(fccqp_solver *s, const double *dQ, const double *db, const doub
   // faster than one even when the chip is otherwise idle: 92.4 against 90.5 us cold with 100 iterations, 43.7
   // against 47.3 us warm with the paper's 15, tools/coop_bench.py: the diagonal tiles, the barriers and the
   // dependent chain of an ADMM iteration are serial either way.)
-  const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s) && fccqp::fused_pointers_ok(a);
-  const bool can_coop = fccqp::coop_supported(s->n, s->m, s->nc, s->s);
+  // (a run-time compiled kernel stands in for the built-in one of its kind; its float-storage instantiation is
+  // compiled on first use, and a shape whose float kernel cannot be had runs that solve on the generic kernel)
+  bool jit_ready = s->jit_kind != 0;
+  if (jit_ready && qa_f32) {
+    if (!s->jit_f32_tried) {
+      s->jit_f32_tried = true;
+      std::string why;
+      s->jit_f32_ok = fccqp::jit::acquire(s->jit_kind == FCCQP_KERNEL_FUSED ? fccqp::jit::kFused : fccqp::jit::kCoop, s->n, s->m,
+                                          s->nc, s->s, true, &s->jit_f32, &why);
+      if (!s->jit_f32_ok) s->err = "run-time compilation of the fp32-storage kernel failed (" + why + "): generic kernel";
+    }
+    jit_ready = s->jit_f32_ok;
+  }
+  const bool can_fuse = (fccqp::fused_supported(s->n, s->m, s->nc, s->s) && fccqp::fused_pointers_ok(a)) ||
+                        (jit_ready && s->jit_kind == FCCQP_KERNEL_FUSED);
+  const bool can_coop = fccqp::coop_supported(s->n, s->m, s->nc, s->s) || (jit_ready && s->jit_kind == FCCQP_KERNEL_COOP);
   int kernel = s->kernel_request;
+  if (kernel == FCCQP_KERNEL_FUSED_SPLIT && s->jit_kind != 0)
+    return fail(s, FCCQP_ERR_UNSUPPORTED, "the two-launch form exists only for shapes compiled into the library");
   if ((kernel == FCCQP_KERNEL_FUSED || kernel == FCCQP_KERNEL_FUSED_SPLIT) && !can_fuse)
     return fail(s, FCCQP_ERR_UNSUPPORTED, "no fused kernel for this shape");
   if (kernel == FCCQP_KERNEL_COOP && !can_coop)
@@ -279,7 +302,10 @@ int enqueue_impl(fccqp_solver *s, const double *dQ, const double *db, const doub
   s->timed = s->kernel_timing && !defer_fallback;
   if (s->timed) HIP_TRY(s, hipEventRecord(s->ev0, stream));
   hipError_t e;
-  if (kernel == FCCQP_KERNEL_COOP) {
+  if (jit_ready && kernel == s->jit_kind) {
+    s->kernel_used = kernel;
+    e = fccqp::jit::launch(qa_f32 ? s->jit_f32 : s->jit_f64, a, stream);
+  } else if (kernel == FCCQP_KERNEL_COOP) {
     s->kernel_used = FCCQP_KERNEL_COOP;
     e = fccqp::launch_coop(a, stream, qa_f32);
   } else if (want_fused) {
@@ -549,6 +575,28 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
         (void)hipHostFree(h);
       }
     }
+    // A shape without a compiled-in specialised kernel: instantiate one now (fccqp_jit.cpp) -- here and not in the first
+    // solve, which may sit in a control loop.  One-wave kernel first; a shape it does not take, or takes only with
+    // register spills, tries the cooperative kernel.  Failure is not an error: the generic kernel serves every shape.
+    if (!fccqp::fused_supported(num_vars, num_equality_constraints, nc, lambda_c_start) &&
+        !fccqp::coop_supported(num_vars, num_equality_constraints, nc, lambda_c_start) && fccqp::jit::enabled()) {
+      std::string why_f, why_c;
+      fccqp::jit::Kernel kf, kc;
+      const bool qf = fccqp::jit::qualifies(fccqp::jit::kFused, num_vars, num_equality_constraints, nc, lambda_c_start, nullptr);
+      const bool qc = fccqp::jit::qualifies(fccqp::jit::kCoop, num_vars, num_equality_constraints, nc, lambda_c_start, nullptr);
+      const bool have_f = qf && fccqp::jit::acquire(fccqp::jit::kFused, num_vars, num_equality_constraints, nc, lambda_c_start, false, &kf, &why_f);
+      if (have_f && kf.scratch_bytes == 0) {
+        s->jit_kind = FCCQP_KERNEL_FUSED; s->jit_f64 = kf;
+      } else if (qc && fccqp::jit::acquire(fccqp::jit::kCoop, num_vars, num_equality_constraints, nc, lambda_c_start, false, &kc, &why_c) &&
+                 kc.scratch_bytes == 0) {
+        s->jit_kind = FCCQP_KERNEL_COOP; s->jit_f64 = kc;
+      } else if (have_f) {
+        s->jit_kind = FCCQP_KERNEL_FUSED; s->jit_f64 = kf;       // (spills registers; still well ahead of the generic kernel)
+      } else if (qf || qc) {
+        s->err = "no run-time compiled kernel for this shape (" + (why_f.empty() ? why_c : why_f) + "): generic kernel";
+      }
+      (void)hipGetLastError();
+    }
     return FCCQP_OK;
   }();
   if (rc != FCCQP_OK) {
@@ -622,7 +670,8 @@ int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use) {
     *kernel_in_use = s->kernel_used;
     return FCCQP_OK;
   }
-  const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s), can_coop = fccqp::coop_supported(s->n, s->m, s->nc, s->s);
+  const bool can_fuse = fccqp::fused_supported(s->n, s->m, s->nc, s->s) || s->jit_kind == FCCQP_KERNEL_FUSED,
+             can_coop = fccqp::coop_supported(s->n, s->m, s->nc, s->s) || s->jit_kind == FCCQP_KERNEL_COOP;
   int k = s->kernel_request;
   if (k == FCCQP_KERNEL_AUTO) {
     k = can_fuse ? FCCQP_KERNEL_FUSED : (can_coop ? FCCQP_KERNEL_COOP : FCCQP_KERNEL_GENERIC);
@@ -637,7 +686,49 @@ int fccqp_kernel_for_shape(int num_vars, int num_equality_constraints, int nc, i
   if (num_vars + num_equality_constraints > fccqp::kGenericMaxN) return -FCCQP_ERR_UNSUPPORTED;
   if (fccqp::fused_supported(num_vars, num_equality_constraints, nc, lambda_c_start)) return FCCQP_KERNEL_FUSED;
   if (fccqp::coop_supported(num_vars, num_equality_constraints, nc, lambda_c_start)) return FCCQP_KERNEL_COOP;
+  if (fccqp::jit::enabled()) {      // what AUTO runs once fccqp_create has compiled the shape's kernel
+    if (fccqp::jit::qualifies(fccqp::jit::kFused, num_vars, num_equality_constraints, nc, lambda_c_start, nullptr)) return FCCQP_KERNEL_FUSED;
+    if (fccqp::jit::qualifies(fccqp::jit::kCoop, num_vars, num_equality_constraints, nc, lambda_c_start, nullptr)) return FCCQP_KERNEL_COOP;
+  }
   return FCCQP_KERNEL_GENERIC;
+}
+int fccqp_kernel_origin_for_shape(int num_vars, int num_equality_constraints, int nc, int lambda_c_start) {
+  const int k = fccqp_kernel_for_shape(num_vars, num_equality_constraints, nc, lambda_c_start);
+  if (k < 0) return k;
+  if (fccqp::fused_supported(num_vars, num_equality_constraints, nc, lambda_c_start) ||
+      fccqp::coop_supported(num_vars, num_equality_constraints, nc, lambda_c_start))
+    return FCCQP_ORIGIN_BUILTIN;
+  return k == FCCQP_KERNEL_GENERIC ? FCCQP_ORIGIN_GENERIC_ONLY : FCCQP_ORIGIN_JIT;
+}
+int fccqp_jit_prepare(int num_vars, int num_equality_constraints, int nc, int lambda_c_start) {
+  const int k = fccqp_kernel_for_shape(num_vars, num_equality_constraints, nc, lambda_c_start);
+  if (k < 0) return k;
+  if (fccqp::fused_supported(num_vars, num_equality_constraints, nc, lambda_c_start)) return FCCQP_KERNEL_FUSED;
+  if (fccqp::coop_supported(num_vars, num_equality_constraints, nc, lambda_c_start)) return FCCQP_KERNEL_COOP;
+  std::string why;
+  if (fccqp::jit::qualifies(fccqp::jit::kFused, num_vars, num_equality_constraints, nc, lambda_c_start, nullptr) &&
+      fccqp::jit::prepare(fccqp::jit::kFused, num_vars, num_equality_constraints, nc, lambda_c_start, false, &why))
+    return FCCQP_KERNEL_FUSED;
+  if (fccqp::jit::qualifies(fccqp::jit::kCoop, num_vars, num_equality_constraints, nc, lambda_c_start, nullptr) &&
+      fccqp::jit::prepare(fccqp::jit::kCoop, num_vars, num_equality_constraints, nc, lambda_c_start, false, &why))
+    return FCCQP_KERNEL_COOP;
+  if (!why.empty()) std::fprintf(stderr, "fccqp_jit_prepare(%d, %d, %d, %d): %s\n", num_vars, num_equality_constraints, nc, lambda_c_start, why.c_str());
+  return -FCCQP_ERR_UNSUPPORTED;
+}
+int fccqp_get_kernel_origin(const fccqp_solver *s, int *origin) {
+  if (!s || !origin) return FCCQP_ERR_INVALID_ARG;
+  if (s->jit_kind != 0) *origin = FCCQP_ORIGIN_JIT;
+  else if (fccqp::fused_supported(s->n, s->m, s->nc, s->s) || fccqp::coop_supported(s->n, s->m, s->nc, s->s)) *origin = FCCQP_ORIGIN_BUILTIN;
+  else *origin = FCCQP_ORIGIN_GENERIC_ONLY;
+  return FCCQP_OK;
+}
+int fccqp_set_jit(int enabled) {
+  fccqp::jit::set_enabled(enabled != 0);
+  return FCCQP_OK;
+}
+int fccqp_debug_jit_forget(void) {
+  fccqp::jit::forget();
+  return FCCQP_OK;
 }
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc, int *lambda_c_start,
                     int *batch, int *device) {

@@ -296,7 +296,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     if (lane < 16) L[SH::kRcp + 16 * Pn + col] = rmine;
     if (bad && lane == 0) iflags[0] = 1;
   };
-  if constexpr (SH::ownC(0) == WV) factor_diag(std::integral_constant<int, 0>{});
+  if constexpr (SH::ownC(0) == WV) factor_diag(int_c<0>{});
   wg_barrier();
   static_for<0, NRB>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
         for (int r = 0; r < 4; ++r)
           if (16 * P + 4 * r < N)
             C[P + 1][P + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[r] * nrv[r], C[P][P + 1][r], C[P + 1][P + 1], 0, 0, 0);
-        factor_diag(std::integral_constant<int, P + 1>{});
+        factor_diag(int_c<P + 1>{});
       }
 #pragma unroll
       for (int I = P + 1; I < NRB; ++I) {
@@ -508,7 +508,7 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
     }
     if (bad && lane == 0) iflags[1] = 1;
   };
-  if constexpr (SH::ownX(0) == WV) factor_diag(std::integral_constant<int, 0>{});
+  if constexpr (SH::ownX(0) == WV) factor_diag(int_c<0>{});
   wg_barrier();
   static_for<0, NW>([&](auto pc) {
     constexpr int P = decltype(pc)::value;
@@ -544,7 +544,7 @@ __device__ __forceinline__ void coop_factor_store(lds_f64 *L, const int lane, co
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           C[P + 1][P + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[r] * -rv[r], C[P][P + 1][r], C[P + 1][P + 1], 0, 0, 0);
-        factor_diag(std::integral_constant<int, P + 1>{});
+        factor_diag(int_c<P + 1>{});
       }
 #pragma unroll
       for (int I = P + 1; I < NW; ++I) {
@@ -924,9 +924,9 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       bool left = false;
 #pragma nounroll
       while (iter < max_iter) {
-        if (iteration(std::integral_constant<int, 1>{})) { left = true; break; }
+        if (iteration(int_c<1>{})) { left = true; break; }
         if (++iter >= max_iter) break;
-        if (iteration(std::integral_constant<int, 0>{})) { left = true; break; }
+        if (iteration(int_c<0>{})) { left = true; break; }
         ++iter;
       }
       // (`iter` iterations ran; the last one's words are in Wq either way)

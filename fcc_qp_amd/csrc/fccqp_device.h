@@ -1,7 +1,9 @@
 // fccqp_device.h -- kernel argument block and launch entry points shared by the C ABI
 // implementation (fccqp_capi.cpp) and the gfx950 kernels (*.hip).  Internal header.
 #pragma once
+#ifndef __HIPCC_RTC__            // (hiprtc, fccqp_jit.cpp: the runtime's device header is built in)
 #include <hip/hip_runtime.h>
+#endif
 
 namespace fccqp {
 
@@ -152,6 +154,7 @@ constexpr int kFlagPresolveCod = 16;
 constexpr int kFlagEqResidual = 32;
 constexpr int kFlagPresolveCg = 64;
 
+#ifndef __HIPCC_RTC__            // host-side launch entry points: not part of a run-time compiled kernel
 // ---- generic kernel (fccqp_generic.hip) -----------------------------------------------------
 // Largest KKT size N = n + m the generic kernel handles (8 register slots x 64 lanes; the reference's
 // shapes are N = 98 and, in BASELINE configs[3], N = 174).  Round 2 had withdrawn N > 256 after sporadically
@@ -196,5 +199,7 @@ hipError_t launch_fused_split(const KernelArgs &a, hipStream_t stream, bool qa_f
 bool coop_supported(int n, int m, int nc, int s);
 int coop_resident_workgroups(int n, int m, int nc, int s, int compute_units);
 hipError_t launch_coop(const KernelArgs &a, hipStream_t stream, bool qa_f32);
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace fccqp

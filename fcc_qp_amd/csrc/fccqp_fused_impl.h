@@ -54,8 +54,17 @@
 // it (pseudo-inverse rule).  Parity with the reference-order oracle is ~1e-13 relative on the
 // walking-shape workloads.
 #pragma once
+// (run-time compilation, fccqp_jit.cpp: hiprtc has no system headers; what this file needs of them is spelled out)
+#ifndef __HIPCC_RTC__
 #include <cfloat>
-#include <type_traits>
+#else
+#ifndef DBL_MIN
+#define DBL_MIN 2.2250738585072014e-308
+#endif
+#ifndef HUGE_VAL
+#define HUGE_VAL __builtin_huge_val()
+#endif
+#endif
 
 #include "fccqp_device.h"
 
@@ -63,6 +72,8 @@ namespace fccqp {
 namespace fused {
 
 constexpr int kWave = 64;
+// compile-time loop index handed to the body of static_for (std::integral_constant without <type_traits>)
+template <int V> struct int_c { static constexpr int value = V; };
 // presolve: smallest pivot of W = I - rho G (eigenvalues in (0, 1]) still taken as non-singular.
 // A pivot p amplifies the ~1e-16 error of rho G by 1/p; below this the instance goes to the COD
 // fallback, whose minimum-norm solution is what the reference returns for a singular K.
@@ -76,7 +87,7 @@ using lds_d2 = __attribute__((address_space(3))) d2;
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (I < E) {
-    f(std::integral_constant<int, I>{});
+    f(int_c<I>{});
     static_for<I + 1, E>(f);
   }
 }

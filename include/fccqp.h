@@ -164,10 +164,43 @@ int fccqp_set_self_check(fccqp_solver *s, int enabled);
 int fccqp_get_kernel(const fccqp_solver *s, int *kernel_in_use);
 /* Which kernel FCCQP_KERNEL_AUTO takes for a shape in THIS build of the library (no handle, no device needed):
  * FCCQP_KERNEL_FUSED or FCCQP_KERNEL_COOP for the constructor arguments listed in fused_shapes.def / coop_shapes.def
- * when the library was built, FCCQP_KERNEL_GENERIC for every other valid shape (several times slower: add the shape
- * and rebuild), a negative status code (-FCCQP_ERR_SHAPE, -FCCQP_ERR_UNSUPPORTED) for arguments
- * fccqp_create would refuse. */
+ * when the library was built and for every shape that qualifies for run-time compilation (below),
+ * FCCQP_KERNEL_GENERIC for every other valid shape (several times slower), a negative status code
+ * (-FCCQP_ERR_SHAPE, -FCCQP_ERR_UNSUPPORTED) for arguments fccqp_create would refuse. */
 int fccqp_kernel_for_shape(int num_vars, int num_equality_constraints, int nc, int lambda_c_start);
+
+/* ---- run-time shape specialisation -------------------------------------------------------------------------------
+ * The reference's constructor takes its sizes at run time (FCCQP::FCCQP, src/fcc_qp.cpp:24-55): nothing is a build
+ * option there.  Here the fast kernels are templates on the sizes; for a shape that is not compiled in, fccqp_create
+ * instantiates the template IN PROCESS with hiprtc (the kernel headers travel inside the library as text; no child
+ * process), loads the code object and keeps it in a disk cache ($FCCQP_JIT_CACHE_DIR, else $XDG_CACHE_HOME/fccqp_jit,
+ * else ~/.cache/fccqp_jit, else /tmp/fccqp_jit_<uid>) keyed by shape, storage type, library version, compile flags, a
+ * hash of the kernel sources and the hiprtc version: the first create of a new shape costs a few seconds, every later
+ * one (any process) a file read.  One-wave kernel for num_vars <= 63, num_equality_constraints <= 64, <= 16 contacts;
+ * else the cooperative kernel for num_vars <= ~118 (<= 8 contacts above 64 variables); nc > 0 in both.  If the shape
+ * does not qualify or compilation is not possible (no libhiprtc, a requirement of the kernel's Shape not met), the
+ * handle uses the generic kernel and fccqp_last_error(handle) says why -- fccqp_create still returns FCCQP_OK.
+ * FCCQP_JIT=0 in the environment, or fccqp_set_jit(0), switches the mechanism off (process-wide). */
+enum {
+  FCCQP_ORIGIN_BUILTIN = 0,   /* compiled into the library (fused_shapes.def / coop_shapes.def), or the generic kernel */
+  FCCQP_ORIGIN_JIT = 1,       /* instantiated at run time for this shape */
+  FCCQP_ORIGIN_GENERIC_ONLY = 2  /* no specialised kernel can be had for the shape: generic kernel */
+};
+/* Where the specialised kernel of a shape comes from in this build (no handle, no device, nothing compiled):
+ * FCCQP_ORIGIN_BUILTIN for a listed shape, FCCQP_ORIGIN_JIT for a shape that qualifies for run-time compilation (and
+ * the mechanism is on), FCCQP_ORIGIN_GENERIC_ONLY otherwise; negative status codes as fccqp_kernel_for_shape.
+ * fccqp_kernel_for_shape answers FCCQP_KERNEL_FUSED / _COOP for a FCCQP_ORIGIN_JIT shape: what AUTO runs once the
+ * kernel is compiled. */
+int fccqp_kernel_origin_for_shape(int num_vars, int num_equality_constraints, int nc, int lambda_c_start);
+/* Compiles the specialised kernel of a shape into the disk cache now (or finds it there): what fccqp_create would do,
+ * without a handle and without a GPU -- e.g. at install time.  Returns FCCQP_KERNEL_FUSED / FCCQP_KERNEL_COOP, or a
+ * negative status code (-FCCQP_ERR_UNSUPPORTED: the shape has no run-time kernel or compilation failed). */
+int fccqp_jit_prepare(int num_vars, int num_equality_constraints, int nc, int lambda_c_start);
+/* FCCQP_ORIGIN_* of the specialised kernel this handle holds (FCCQP_ORIGIN_GENERIC_ONLY: none). */
+int fccqp_get_kernel_origin(const fccqp_solver *s, int *origin);
+int fccqp_set_jit(int enabled);          /* process-wide; affects handles created afterwards */
+/* tests: forget the code objects held in memory, so that the next create reads the disk cache */
+int fccqp_debug_jit_forget(void);
 int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
                     int *lambda_c_start, int *batch, int *device);
 

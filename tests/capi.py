@@ -16,6 +16,7 @@ OK, ERR_INVALID_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_FRICTION,
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_COOP = 0, 1, 2, 3, 4
 FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD, FLAG_EQ_RESIDUAL, FLAG_PRESOLVE_CG = 1, 2, 4, 8, 16, 32, 64
 TIMING_NONE, TIMING_DEVICE_EVENTS, TIMING_HOST_CLOCK = 0, 1, 2
+ORIGIN_BUILTIN, ORIGIN_JIT, ORIGIN_GENERIC_ONLY = 0, 1, 2
 
 
 class Options(C.Structure):
@@ -77,6 +78,10 @@ def lib():
         L.fccqp_set_state.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.fccqp_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.fccqp_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+        L.fccqp_kernel_origin_for_shape.argtypes = [C.c_int] * 4
+        L.fccqp_jit_prepare.argtypes = [C.c_int] * 4
+        L.fccqp_get_kernel_origin.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.fccqp_set_jit.argtypes = [C.c_int]
         L.fccqp_phase_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.fccqp_debug_phase_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_longlong]
         _lib = L
@@ -129,6 +134,14 @@ class Solver:
 
     def set_kernel_timing(self, on):
         self._ck(self.L.fccqp_set_kernel_timing(self.h, int(bool(on))), "set_kernel_timing")
+
+    def kernel_origin(self):
+        o = C.c_int()
+        self._ck(self.L.fccqp_get_kernel_origin(self.h, C.byref(o)), "get_kernel_origin")
+        return o.value
+
+    def last_error(self):
+        return self.L.fccqp_last_error(self.h).decode()
 
     def kernel(self):
         k = C.c_int()

@@ -20,6 +20,16 @@ if os.path.isdir(_logdir) and os.access(_logdir, os.W_OK):
     os.environ.setdefault("AMD_LOG_LEVEL_FILE", os.path.join(_logdir, "hip_runtime_%d.log" % os.getpid()))
 
 
+# Run-time shape specialisation (fcc_qp_amd/csrc/fccqp_jit.cpp) is OFF for the suite and switched on by the tests that
+# are about it (tests/test_jit_cpu.py, tests/test_gpu_jit.py): dozens of tests create unlisted shapes precisely to
+# exercise the generic kernel under FCCQP_KERNEL_AUTO, and a few seconds of hiprtc per shape would be spent on each.
+# Its disk cache goes to a directory of this run.
+os.environ.setdefault("FCCQP_JIT", "0")
+if "FCCQP_JIT_CACHE_DIR" not in os.environ:
+    import tempfile
+    os.environ["FCCQP_JIT_CACHE_DIR"] = tempfile.mkdtemp(prefix="fccqp_jit_test_")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
     # A fresh clone has no built artefacts (they are git-ignored): build them once, in tree, exactly

@@ -101,8 +101,8 @@ def test_kernel_for_shape_needs_no_device():
     L = C.lib()
     assert L.fccqp_kernel_for_shape(60, 38, 12, 38) == C.KERNEL_FUSED          # reference harness shape
     assert L.fccqp_kernel_for_shape(114, 60, 24, 66) == C.KERNEL_COOP          # large shape
-    assert L.fccqp_kernel_for_shape(61, 38, 12, 38) == C.KERNEL_GENERIC
-    assert L.fccqp_kernel_for_shape(20, 5, 0, 0) == C.KERNEL_GENERIC
+    assert L.fccqp_kernel_for_shape(61, 38, 12, 38) == C.KERNEL_GENERIC        # (run-time compilation is off in the suite:
+    assert L.fccqp_kernel_for_shape(20, 5, 0, 0) == C.KERNEL_GENERIC           #  tests/conftest.py; tests/test_jit_cpu.py)
     assert L.fccqp_kernel_for_shape(10, 4, 4, 0) == -C.ERR_SHAPE               # nc % 3
     assert L.fccqp_kernel_for_shape(10, 4, 6, 6) == -C.ERR_SHAPE               # lambda_c_start + nc > num_vars
     assert L.fccqp_kernel_for_shape(400, 113, 12, 100) == -C.ERR_UNSUPPORTED   # n + m > 512

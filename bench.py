@@ -339,6 +339,15 @@ def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup
     # a humanoid-sized shape no specialised kernel is compiled for: 44 DoF, 38 inputs, 12 contacts -> FCCQP(148, 74, 36, 82),
     # N = 222: the generic kernel with the KKT matrix in its per-block global workspace (198 < N <= 512)
     run("mid_shape", P.MID, "W-sat", P.HARNESS_OPTIONS, distinct=16, parity_k=8, steps=4, warmup=1)
+    # a shape the library was NOT built for, FCCQP(47, 30, 9, 30): fccqp_create compiles the one-wave kernel for it at run
+    # time (hiprtc in process, disk cache: fcc_qp_amd/csrc/fccqp_jit.cpp); beside it the generic kernel such a shape ran on
+    # through round 4.  create_s: wall time of the handle's creation (first in this process: compile or disk cache).
+    t_c = time.time()
+    sv, _, _ = run("jit_shape", P.SMALL, "W-sat", P.HARNESS_OPTIONS, parity_k=32)
+    out["jit_shape"]["create_plus_run_s"] = time.time() - t_c
+    out["jit_shape"]["kernel_origin"] = {0: "builtin", 1: "jit", 2: "generic_only"}.get(sv.kernel_origin(), "?")
+    del sv
+    run("jit_shape_generic", P.SMALL, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_GENERIC, parity_k=32, steps=8, warmup=2)
     out["two_streams"] = two_streams(F, P, torch, dev, dev_index, log)
     out["batch_sweep"] = batch_sweep(F, P, torch, dev, dev_index, log)
     out["single_instance"] = single_instance(F, P, log)

@@ -34,9 +34,9 @@ except ImportError as exc:  # fail loudly: the HIP extension IS the product
         f"There is no CPU fallback. Original error: {exc}") from exc
 
 from . import problems  # noqa: E402,F401
-from .batch import result_tensors, solve_tensors  # noqa: E402,F401
+from .batch import result_tensors, solve_tensors, solve_tensors_sharded  # noqa: E402,F401
 
 LIB_PATH = _os.path.join(_HERE, "libfccqp_hip.so")
 
 __all__ = ["FCCQP", "FCCQPBatch", "FCCQPBatchSolution", "FCCQPDetails", "FCCQPError", "FCCQPOptions",
-           "FCCQPSharded", "FCCQPSolution", "device_count", "kernel_for_shape", "problems", "solve_tensors", "result_tensors", "LIB_PATH"]
+           "FCCQPSharded", "FCCQPSolution", "device_count", "kernel_for_shape", "problems", "solve_tensors", "solve_tensors_sharded", "result_tensors", "LIB_PATH"]

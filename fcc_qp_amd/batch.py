@@ -110,3 +110,34 @@ def result_tensors(solver) -> Dict[str, "object"]:
         "eps_bounds": metrics[0], "eps_friction_cone": metrics[1],
         "bounds_viol": metrics[2], "friction_cone_viol": metrics[3],
     }
+
+
+def solve_tensors_sharded(sharded, shard_tensors, streams=None):
+    """Enqueue an ``FCCQPSharded`` on device-resident data: ``shard_tensors[g]`` = the seven float64 arrays of shard
+    ``g`` -- the instances ``[sharded.shard_begin(g), sharded.shard_begin(g + 1))`` -- on ``cuda:sharded.device_of(g)``
+    (torch tensors, ``__dlpack__`` or ``__cuda_array_interface__`` producers).  Returns immediately; ``sharded.Synchronize()``
+    waits, ``sharded.GetSolution()`` gathers.  ``streams``: one torch stream per shard (default: each shard's own stream).
+    One process driving several GPUs at their device-resident rate (the host-pointer ``Solve`` is bound by the PCIe copies)."""
+    import torch
+
+    G = sharded.shards
+    if len(shard_tensors) != G:
+        raise ValueError(f"solve_tensors_sharded: {len(shard_tensors)} tensor sets for {G} shards")
+    n, m, nc = sharded.num_vars, sharded.num_equality_constraints, sharded.nc
+    ptrs = []
+    for g, tens in enumerate(shard_tensors):
+        tens = tuple(as_device_tensor(t) for t in tens)
+        if len(tens) != 7:
+            raise ValueError("solve_tensors_sharded: seven arrays per shard (Q, b, A_eq, b_eq, friction_coeffs, lb, ub)")
+        nb = (sharded.shard_begin(g + 1) if g + 1 < G else sharded.batch) - sharded.shard_begin(g)
+        want = {"Q": (nb, n, n), "b": (nb, n), "A_eq": (nb, m, n), "b_eq": (nb, m), "friction_coeffs": (nb, nc // 3),
+                "lb": (nb, n), "ub": (nb, n)}
+        for name, t in zip(_NAMES, tens):
+            if not t.is_cuda or t.device.index != sharded.device_of(g):
+                raise ValueError(f"solve_tensors_sharded: shard {g} {name} is not on cuda:{sharded.device_of(g)}")
+            if t.dtype != torch.float64 or not t.is_contiguous():
+                raise ValueError(f"solve_tensors_sharded: shard {g} {name} must be a contiguous float64 array")
+            if tuple(t.shape) != want[name] and not (t.numel() == 0 and 0 in want[name]):
+                raise ValueError(f"solve_tensors_sharded: shard {g} {name} has shape {tuple(t.shape)}, expected {want[name]}")
+        ptrs.append([int(t.data_ptr()) for t in tens])
+    sharded.SolveDevice(ptrs, [] if streams is None else [int(s.cuda_stream) for s in streams])

@@ -3,10 +3,11 @@
 // delegated to the HIP library.  Plain C++17, no HIP headers: this file only sees the C ABI.
 #include "fcc_qp.hpp"
 
-#include <thread>
-
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "fccqp.h"
 
@@ -226,6 +227,72 @@ long long FCCQPBatch::AlgorithmicBytes() const {
 }
 
 // ---------------------------------------------------------------------------- FCCQPSharded
+// One persistent host thread per shard: created with the object, woken for every call that has per-shard work (a
+// std::thread per shard and call, as through round 4, costs ~30 us each -- more than a small solve).  run() hands
+// fn(g) to thread g for every g and returns when all are done; one run() at a time (the class is as non-reentrant as
+// the reference's, src/fcc_qp.hpp:130-171).
+class FCCQPSharded::Workers {
+ public:
+  explicit Workers(std::size_t count) : rc_(count, FCCQP_OK) {
+    threads_.reserve(count);
+    for (std::size_t g = 0; g < count; ++g) threads_.emplace_back([this, g] { loop(g); });
+  }
+  ~Workers() {
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      stop_ = true;
+      ++generation_;
+    }
+    wake_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+  // returns the status codes of fn(0) .. fn(count - 1)
+  const std::vector<int> &run(const std::function<int(std::size_t)> &fn) {
+    std::unique_lock<std::mutex> lock(m_);
+    fn_ = &fn;
+    pending_ = threads_.size();
+    ++generation_;
+    wake_.notify_all();
+    done_.wait(lock, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+    return rc_;
+  }
+
+ private:
+  void loop(std::size_t g) {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<int(std::size_t)> *fn = nullptr;
+      {
+        std::unique_lock<std::mutex> lock(m_);
+        wake_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+        fn = fn_;
+      }
+      const int rc = (*fn)(g);
+      {
+        std::lock_guard<std::mutex> lock(m_);
+        rc_[g] = rc;
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::mutex m_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread> threads_;
+  std::vector<int> rc_;
+  const std::function<int(std::size_t)> *fn_ = nullptr;
+  std::size_t pending_ = 0;
+  unsigned long long generation_ = 0;
+  bool stop_ = false;
+};
+
+void FCCQPSharded::on_every_shard(const std::function<int(std::size_t)> &fn, const char *where) const {
+  const std::vector<int> &rc = workers_->run(fn);
+  for (std::size_t g = 0; g < h_.size(); ++g) check(rc[g], h_[g], where);
+}
+
 FCCQPSharded::FCCQPSharded(int num_vars, int num_equality_constraints, int nc, int lambda_c_start,
                            int batch, const std::vector<int> &devices)
     : n_vars_(num_vars), n_eq_(num_equality_constraints), nc_(nc), lambda_c_start_(lambda_c_start),
@@ -241,8 +308,10 @@ FCCQPSharded::FCCQPSharded(int num_vars, int num_equality_constraints, int nc, i
       check(rc, nullptr, "FCCQPSharded::FCCQPSharded");
     }
   }
+  workers_.reset(new Workers(devices.size()));
 }
 FCCQPSharded::~FCCQPSharded() {
+  workers_.reset();                 // (joins the threads before the handles they use go away)
   for (auto *h : h_) fccqp_destroy(h);
 }
 void FCCQPSharded::set_options(FCCQPOptions opt) {
@@ -263,21 +332,63 @@ void FCCQPSharded::set_kernel_timing(bool enabled) {
 void FCCQPSharded::Solve(const double *Q, const double *b, const double *A_eq, const double *b_eq,
                          const double *friction_coeffs, int n_friction, const double *lb,
                          const double *ub) {
-  const size_t n = (size_t)n_vars_, m = (size_t)n_eq_, G = h_.size();
-  std::vector<int> rc(G, FCCQP_OK);
-  std::vector<std::thread> th;
-  th.reserve(G);
-  for (size_t g = 0; g < G; ++g) {
-    th.emplace_back([&, g] {
-      const size_t lo = (size_t)shard_begin((int)g);
-      rc[g] = fccqp_solve(h_[g], Q + lo * n * n, b + lo * n, A_eq ? A_eq + lo * m * n : nullptr,
-                          b_eq ? b_eq + lo * m : nullptr,
-                          friction_coeffs ? friction_coeffs + lo * (size_t)n_friction : nullptr, n_friction,
-                          lb + lo * n, ub + lo * n);
-    });
+  const size_t n = (size_t)n_vars_, m = (size_t)n_eq_;
+  on_every_shard([&](size_t g) {
+    const size_t lo = (size_t)shard_begin((int)g);
+    return fccqp_solve(h_[g], Q + lo * n * n, b + lo * n, A_eq ? A_eq + lo * m * n : nullptr,
+                       b_eq ? b_eq + lo * m : nullptr,
+                       friction_coeffs ? friction_coeffs + lo * (size_t)n_friction : nullptr, n_friction,
+                       lb + lo * n, ub + lo * n);
+  }, "FCCQPSharded::Solve");
+}
+
+void FCCQPSharded::SolveDevice(const std::vector<ShardDeviceInputs> &in) {
+  if (in.size() != h_.size()) throw std::invalid_argument("FCCQPSharded::SolveDevice: one set of device pointers per shard");
+  // (enqueue only -- microseconds per shard: no threads)
+  for (size_t g = 0; g < h_.size(); ++g)
+    check(fccqp_solve_device(h_[g], in[g].Q, in[g].b, in[g].A_eq, in[g].b_eq, in[g].friction_coeffs, in[g].lb, in[g].ub,
+                             in[g].stream),
+          h_[g], "FCCQPSharded::SolveDevice");
+}
+
+std::vector<FCCQPSharded::ShardDeviceInputs> FCCQPSharded::SliceDeviceBatch(const double *dQ, const double *db, const double *dA_eq,
+                                                                            const double *db_eq, const double *dfriction,
+                                                                            const double *dlb, const double *dub) const {
+  const size_t n = (size_t)n_vars_, m = (size_t)n_eq_, nf = (size_t)(nc_ / 3);
+  std::vector<ShardDeviceInputs> out(h_.size());
+  for (size_t g = 0; g < h_.size(); ++g) {
+    const size_t lo = (size_t)shard_begin((int)g);
+    out[g].Q = dQ + lo * n * n;
+    out[g].b = db + lo * n;
+    out[g].A_eq = dA_eq ? dA_eq + lo * m * n : nullptr;
+    out[g].b_eq = db_eq ? db_eq + lo * m : nullptr;
+    out[g].friction_coeffs = dfriction ? dfriction + lo * nf : nullptr;
+    out[g].lb = dlb + lo * n;
+    out[g].ub = dub + lo * n;
   }
-  for (auto &t : th) t.join();
-  for (size_t g = 0; g < G; ++g) check(rc[g], h_[g], "FCCQPSharded::Solve");
+  return out;
+}
+
+void FCCQPSharded::SolveAsync(const double *Q, const double *b, const double *A_eq, const double *b_eq,
+                              const double *friction_coeffs, int n_friction, const double *lb, const double *ub) {
+  const size_t n = (size_t)n_vars_, m = (size_t)n_eq_;
+  // (through the workers: hipMemcpyAsync out of pageable memory blocks, and then the shards' copies should overlap)
+  on_every_shard([&](size_t g) {
+    const size_t lo = (size_t)shard_begin((int)g);
+    return fccqp_solve_async(h_[g], Q + lo * n * n, b + lo * n, A_eq ? A_eq + lo * m * n : nullptr,
+                             b_eq ? b_eq + lo * m : nullptr,
+                             friction_coeffs ? friction_coeffs + lo * (size_t)n_friction : nullptr, n_friction,
+                             lb + lo * n, ub + lo * n);
+  }, "FCCQPSharded::SolveAsync");
+}
+
+void FCCQPSharded::GetZAsync(double *z_pinned) {
+  for (size_t g = 0; g < h_.size(); ++g)
+    check(fccqp_get_z_async(h_[g], z_pinned + (size_t)shard_begin((int)g) * (size_t)n_vars_), h_[g], "FCCQPSharded::GetZAsync");
+}
+
+void FCCQPSharded::Synchronize() {
+  for (auto *h : h_) check(fccqp_synchronize(h), h, "FCCQPSharded::Synchronize");
 }
 
 FCCQPBatchSolution FCCQPSharded::GetSolution() const {
@@ -286,18 +397,10 @@ FCCQPBatchSolution FCCQPSharded::GetSolution() const {
   out.num_vars = n_vars_;
   out.z.assign((size_t)batch_ * (size_t)n_vars_, 0.0);
   std::vector<fccqp_details> d((size_t)batch_);
-  const size_t G = h_.size();
-  std::vector<int> rc(G, FCCQP_OK);
-  std::vector<std::thread> th;
-  th.reserve(G);
-  for (size_t g = 0; g < G; ++g) {
-    th.emplace_back([&, g] {
-      const size_t lo = (size_t)shard_begin((int)g);
-      rc[g] = fccqp_get_solution(h_[g], out.z.data() + lo * (size_t)n_vars_, d.data() + lo);
-    });
-  }
-  for (auto &t : th) t.join();
-  for (size_t g = 0; g < G; ++g) check(rc[g], h_[g], "FCCQPSharded::GetSolution");
+  on_every_shard([&](size_t g) {
+    const size_t lo = (size_t)shard_begin((int)g);
+    return fccqp_get_solution(h_[g], out.z.data() + lo * (size_t)n_vars_, d.data() + lo);
+  }, "FCCQPSharded::GetSolution");
   out.details.reserve((size_t)batch_);
   for (const auto &x : d) out.details.push_back(from_c(x));
   return out;

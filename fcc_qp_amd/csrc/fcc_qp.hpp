@@ -10,6 +10,8 @@
 // device throws.
 #pragma once
 #include <cstddef>
+#include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -200,9 +202,31 @@ class FCCQPSharded {
   void set_kernel_timing(bool enabled);
   FCCQPOptions get_options() const { return options_; }
 
-  // host pointers to the whole batch; n_friction = friction coefficients per instance (>= nc/3)
+  // host pointers to the whole batch; n_friction = friction coefficients per instance (>= nc/3).  Blocking: every
+  // shard's persistent worker thread copies its slice out of (pageable) host memory, solves and waits.
   void Solve(const double *Q, const double *b, const double *A_eq, const double *b_eq,
              const double *friction_coeffs, int n_friction, const double *lb, const double *ub);
+  // Device-resident inputs, asynchronous: shard g's instances [shard_begin(g), shard_begin(g + 1)) lie in the seven
+  // instance-major arrays of in[g], resident on device_of(g); the solve is enqueued on in[g].stream (nullptr: HIP's
+  // default stream; the default argument: the shard's own stream) and the call returns.  This is the path that keeps
+  // several GPUs at their device-resident rate from ONE process (Solve above is bound by the PCIe copies).
+  struct ShardDeviceInputs {
+    const double *Q = nullptr, *b = nullptr, *A_eq = nullptr, *b_eq = nullptr, *friction_coeffs = nullptr, *lb = nullptr,
+                 *ub = nullptr;
+    void *stream = reinterpret_cast<void *>(static_cast<std::ptrdiff_t>(-1));      // FCCQP_STREAM_OWN
+  };
+  void SolveDevice(const std::vector<ShardDeviceInputs> &in);
+  // One instance-major batch resident on ONE device (every shard on that device: tests, or several handles sharing a
+  // GPU): the shard pointers are the base pointers advanced to shard_begin(g).
+  std::vector<ShardDeviceInputs> SliceDeviceBatch(const double *dQ, const double *db, const double *dA_eq, const double *db_eq,
+                                                  const double *dfriction, const double *dlb, const double *dub) const;
+  // Page-locked host memory, asynchronous: every shard enqueues the copies of its slice, its kernel and (GetZAsync)
+  // the copy of its slice of z into `z_pinned` [batch][num_vars] on its own stream and returns; the arrays stay
+  // borrowed until Synchronize().  n_friction must be nc/3 here.  (Pageable arrays work too, but their copies block.)
+  void SolveAsync(const double *Q, const double *b, const double *A_eq, const double *b_eq,
+                  const double *friction_coeffs, int n_friction, const double *lb, const double *ub);
+  void GetZAsync(double *z_pinned);
+  void Synchronize();
   FCCQPBatchSolution GetSolution() const;
   // slowest shard's device time for the last Solve (ms)
   float LastKernelMilliseconds() const;
@@ -220,6 +244,10 @@ class FCCQPSharded {
   const int n_vars_, n_eq_, nc_, lambda_c_start_, batch_;
   std::vector<int> devices_;
   std::vector<fccqp_solver *> h_;
+  // one persistent host thread per shard (created once: a solve call hands every shard's work to its thread and waits)
+  class Workers;
+  std::unique_ptr<Workers> workers_;
+  void on_every_shard(const std::function<int(std::size_t)> &fn, const char *where) const;
 };
 
 }  // namespace fcc_qp

@@ -56,6 +56,22 @@ py::array_t<double> to_numpy(const std::vector<double> &v) {
   return out;
 }
 
+// a float64, C-contiguous array of exactly this shape, borrowed as it is (asynchronous entry points: no converted copy
+// may be made, it would be gone before the device has read it)
+const double *borrowed_f64(const py::array &a, std::initializer_list<py::ssize_t> shape, const char *name) {
+  bool ok = a.dtype().is(py::dtype::of<double>()) && (a.flags() & py::array::c_style) && a.ndim() == (py::ssize_t)shape.size();
+  if (ok) {
+    int k = 0;
+    for (auto d : shape) ok = ok && a.shape(k++) == d;
+  }
+  if (!ok) {
+    std::string s = std::string(name) + " must be a C-contiguous float64 array of shape (";
+    for (auto d : shape) s += std::to_string(d) + ",";
+    throw py::value_error(s + ")");
+  }
+  return static_cast<const double *>(a.data());
+}
+
 template <class T>
 void expect_shape_t(const py::array_t<T, py::array::c_style | py::array::forcecast> &a,
                     std::initializer_list<py::ssize_t> shape, const char *name) {
@@ -221,6 +237,12 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def("set_kernel", &FCCQPBatch::set_kernel)
       .def("set_kernel_timing", &FCCQPBatch::set_kernel_timing, py::arg("enabled"))
       .def("kernel_in_use", &FCCQPBatch::kernel_in_use)
+      .def("kernel_origin", [](const FCCQPBatch &self) {
+        int o = 0;
+        fccqp_get_kernel_origin(self.handle(), &o);
+        return o;
+      }, "0: the specialised kernel of this shape is compiled into the library (or there is none and none is needed), "
+         "1: compiled at run time when the handle was created (include/fccqp.h, FCCQP_ORIGIN_*), 2: generic kernel only")
       .def_property_readonly("batch", &FCCQPBatch::batch)
       .def_property_readonly("num_vars", &FCCQPBatch::num_vars)
       .def_property_readonly("num_equality_constraints", &FCCQPBatch::num_equality_constraints)
@@ -312,6 +334,9 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def("set_kernel_timing", &fcc_qp::FCCQPSharded::set_kernel_timing, py::arg("enabled"))
       .def_property_readonly("batch", &fcc_qp::FCCQPSharded::batch)
       .def_property_readonly("shards", &fcc_qp::FCCQPSharded::shards)
+      .def_property_readonly("num_vars", &fcc_qp::FCCQPSharded::num_vars)
+      .def_property_readonly("num_equality_constraints", &fcc_qp::FCCQPSharded::num_equality_constraints)
+      .def_property_readonly("nc", &fcc_qp::FCCQPSharded::nc)
       .def("shard_begin", &fcc_qp::FCCQPSharded::shard_begin)
       .def("device_of", &fcc_qp::FCCQPSharded::device_of)
       .def(
@@ -339,6 +364,47 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
           py::arg("Q"), py::arg("b"), py::arg("A_eq"), py::arg("b_eq"), py::arg("friction_coeffs"),
           py::arg("lb"), py::arg("ub"),
           "Splits the instance-major host batch over the shards (one host thread per shard), solves, waits.")
+      .def(
+          "SolveDevice",
+          [](fcc_qp::FCCQPSharded &self, const std::vector<std::vector<std::uintptr_t>> &shards, const std::vector<std::uintptr_t> &streams) {
+            if ((int)shards.size() != self.shards()) throw py::value_error("FCCQPSharded.SolveDevice: one list of seven device pointers per shard");
+            if (!streams.empty() && (int)streams.size() != self.shards()) throw py::value_error("FCCQPSharded.SolveDevice: one stream per shard, or none");
+            std::vector<fcc_qp::FCCQPSharded::ShardDeviceInputs> in(shards.size());
+            for (size_t g = 0; g < shards.size(); ++g) {
+              if (shards[g].size() != 7) throw py::value_error("FCCQPSharded.SolveDevice: seven pointers per shard (Q, b, A_eq, b_eq, friction_coeffs, lb, ub)");
+              const auto p = [&](int i) { return reinterpret_cast<const double *>(shards[g][(size_t)i]); };
+              in[g].Q = p(0); in[g].b = p(1); in[g].A_eq = p(2); in[g].b_eq = p(3); in[g].friction_coeffs = p(4); in[g].lb = p(5); in[g].ub = p(6);
+              if (!streams.empty()) in[g].stream = reinterpret_cast<void *>(streams[g]);
+            }
+            self.SolveDevice(in);
+          },
+          py::arg("shards"), py::arg("streams") = std::vector<std::uintptr_t>{},
+          "Asynchronous solve from device-resident float64 arrays: shards[g] = the seven device pointers (ints) of shard g's "
+          "instance-major slice, resident on device_of(g); streams[g] = the HIP stream to enqueue on (default: the shard's own).")
+      .def(
+          "SolveAsync",
+          [](fcc_qp::FCCQPSharded &self, const py::array &Q, const py::array &b, const py::array &A_eq, const py::array &b_eq,
+             const py::array &fr, const py::array &lb, const py::array &ub) {
+            const py::ssize_t B = self.batch(), n = self.num_vars(), mm = self.num_equality_constraints(), nf = self.nc() / 3;
+            const double *pQ = borrowed_f64(Q, {B, n, n}, "Q"), *pb = borrowed_f64(b, {B, n}, "b");
+            const double *pA = mm > 0 ? borrowed_f64(A_eq, {B, mm, n}, "A_eq") : nullptr;
+            const double *pbe = mm > 0 ? borrowed_f64(b_eq, {B, mm}, "b_eq") : nullptr;
+            const double *pf = nf > 0 ? borrowed_f64(fr, {B, nf}, "friction_coeffs") : nullptr;
+            const double *pl = borrowed_f64(lb, {B, n}, "lb"), *pu = borrowed_f64(ub, {B, n}, "ub");
+            py::gil_scoped_release release;
+            self.SolveAsync(pQ, pb, pA, pbe, pf, (int)nf, pl, pu);
+          },
+          py::arg("Q"), py::arg("b"), py::arg("A_eq"), py::arg("b_eq"), py::arg("friction_coeffs"), py::arg("lb"), py::arg("ub"),
+          "Asynchronous solve from C-contiguous float64 host arrays (page-locked ones for copies that overlap): NO conversion "
+          "is made (anything else is a ValueError), and the arrays must stay alive and unchanged until Synchronize().")
+      .def(
+          "GetZAsync",
+          [](fcc_qp::FCCQPSharded &self, py::array &z) {
+            if (!z.writeable()) throw py::value_error("z is read-only");
+            self.GetZAsync(const_cast<double *>(borrowed_f64(z, {(py::ssize_t)self.batch(), (py::ssize_t)self.num_vars()}, "z")));
+          },
+          py::arg("z"), "Enqueues the copy of every shard's z into its rows of `z` ([batch, num_vars] float64, C-contiguous, kept alive until Synchronize()).")
+      .def("Synchronize", &fcc_qp::FCCQPSharded::Synchronize, py::call_guard<py::gil_scoped_release>())
       .def("GetSolution", &fcc_qp::FCCQPSharded::GetSolution)
       .def("LastKernelMilliseconds", &fcc_qp::FCCQPSharded::LastKernelMilliseconds);
 

@@ -58,7 +58,8 @@ class Shape:
 WALKING = Shape(nv=22, nu=10, nh=6, nc=12, ne=10)   # FCCQP(60, 38, 12, 38)
 LARGE = Shape(nv=36, nu=30, nh=0, nc=24, ne=24)     # FCCQP(114, 60, 24, 66)
 MID = Shape(nv=44, nu=38, nh=0, nc=36, ne=30)       # FCCQP(148, 74, 36, 82): humanoid-sized, N = 222 (no specialised kernel)
-SHAPES = {"walking": WALKING, "large": LARGE, "mid": MID}
+SMALL = Shape(nv=18, nu=8, nh=4, nc=9, ne=8)        # FCCQP(47, 30, 9, 30): a smaller biped, NOT in fused_shapes.def (run-time compiled kernel)
+SHAPES = {"walking": WALKING, "large": LARGE, "mid": MID, "small": SMALL}
 
 #: options of the reference harness (fcc_qp_test.py:78-83) -- canonical for all timed runs
 HARNESS_OPTIONS = dict(max_iter=100, rho=5e-5, eps_fcone=1e-6, eps_bound=1e-6)

@@ -77,6 +77,28 @@ int main() {
       sh.set_warm_start(true);
       sh.Solve(Q.data(), b.data(), A.data(), beq.data(), mu.data(), 2, lb.data(), ub.data());
       CHECK(std::fabs(sh.GetSolution().z[0] - sol.z[0] - 0.5) < 1e-9);               // the flag reached the handles
+      sh.set_warm_start(false);
+      // device-resident form: one set of pointers per shard, sliced out of one instance-major batch (compact friction
+      // coefficients: nc / 3 per instance); asynchronous page-locked form: SolveAsync + GetZAsync + Synchronize
+      std::vector<double> mu1(B);
+      for (size_t i = 0; i < B; ++i) mu1[i] = 0.5;
+      const auto slices = sh.SliceDeviceBatch(Q.data(), b.data(), A.data(), beq.data(), mu1.data(), lb.data(), ub.data());
+      CHECK((int)slices.size() == shards);
+      for (int g = 0; g < shards; ++g) CHECK(slices[(size_t)g].Q == Q.data() + (size_t)sh.shard_begin(g) * n * n && slices[(size_t)g].ub == ub.data() + (size_t)sh.shard_begin(g) * n);
+      sh.SolveDevice(slices);
+      sh.Synchronize();
+      const FCCQPBatchSolution dev = sh.GetSolution();
+      CHECK(dev.z == sol.z);                                                         // same instances, same handles
+      std::vector<double> zpin(B * n, -7.0);
+      for (int rep = 0; rep < 3; ++rep) {                                            // (the worker threads are reused)
+        sh.SolveAsync(Q.data(), b.data(), A.data(), beq.data(), mu1.data(), 1, lb.data(), ub.data());
+        sh.GetZAsync(zpin.data());
+        sh.Synchronize();
+        CHECK(zpin == sol.z);
+      }
+      bool refused = false;
+      try { sh.SolveDevice(std::vector<FCCQPSharded::ShardDeviceInputs>((size_t)shards + 1)); } catch (const std::invalid_argument &) { refused = true; }
+      CHECK(refused);
     }
   }
   bool threw = false;

@@ -78,8 +78,9 @@ int fccqp_solve_async(fccqp_solver *s, const double *Q, const double *b, const d
 }
 int fccqp_host_register(void *, size_t) { return FCCQP_OK; }
 int fccqp_host_unregister(void *) { return FCCQP_OK; }
-int fccqp_solve_device(fccqp_solver *, const double *, const double *, const double *, const double *, const double *,
-                       const double *, const double *, void *) { return FCCQP_ERR_NO_DEVICE; }
+// ("device" pointers are host pointers here: the stub reads them like fccqp_solve, nc/3 coefficients per instance)
+int fccqp_solve_device(fccqp_solver *s, const double *Q, const double *b, const double *A, const double *beq, const double *mu,
+                       const double *lb, const double *ub, void *) { return fccqp_solve(s, Q, b, A, beq, mu, s->nc / 3, lb, ub); }
 int fccqp_solve_f32(fccqp_solver *, const float *, const float *, const float *, const float *, const float *, int,
                     const float *, const float *) { return FCCQP_ERR_NO_DEVICE; }
 int fccqp_solve_device_f32(fccqp_solver *, const float *, const float *, const float *, const float *, const float *,

@@ -306,6 +306,57 @@ def test_sharded_solve_equals_unsharded_bit_for_bit(oracle):
             F.FCCQPSharded(60, 38, 12, 38, 8, [0, 1])          # no such device
 
 
+def test_sharded_device_and_pinned_paths_equal_the_unsharded_solve_bit_for_bit():
+    """FCCQPSharded from ONE process at the device-resident rate: SolveDevice (one set of device pointers per shard,
+    asynchronous) and SolveAsync + GetZAsync (page-locked host arrays, every shard's copies and kernel on its own
+    stream) -- three shards on device 0, ragged, cold and warm -- bit-identical to one handle solving the whole batch."""
+    import torch
+    import fcc_qp_amd as F
+    nb = 100
+    B = P.workload("W-mix", nb, P.WALKING)
+    B2 = P.workload("W-mix", nb, P.WALKING, seed0=4000)
+    one = F.FCCQPBatch(60, 38, 12, 38, nb); one.set_options(harness_options(F))
+    one.Solve(*B.arrays()); ref = one.GetSolution()
+    one.set_warm_start(True); one.Solve(*B2.arrays()); wref = one.GetSolution()
+    dev = torch.device("cuda", 0)
+    devices = [0, 0, 0]
+
+    def shard_tensors(sh, batch):
+        cuts = [sh.shard_begin(g) for g in range(sh.shards)] + [nb]
+        return [[torch.from_numpy(np.ascontiguousarray(a[cuts[g]:cuts[g + 1]])).to(dev) for a in batch.arrays()] for g in range(sh.shards)]
+
+    # ---- device pointers per shard
+    sh = F.FCCQPSharded(60, 38, 12, 38, nb, devices); sh.set_options(harness_options(F))
+    t1 = shard_tensors(sh, B)
+    F.solve_tensors_sharded(sh, t1)                       # every shard on its own stream
+    sh.Synchronize(); got = sh.GetSolution()
+    assert np.array_equal(got.z, ref.z) and np.array_equal(got.n_iter, ref.n_iter) and np.array_equal(got.flags, ref.flags)
+    t2 = shard_tensors(sh, B2)
+    streams = [torch.cuda.Stream(device=dev) for _ in devices]
+    sh.set_warm_start(True)
+    F.solve_tensors_sharded(sh, t2, streams=streams)      # the caller's streams
+    sh.Synchronize(); w = sh.GetSolution()
+    assert np.array_equal(w.z, wref.z) and np.array_equal(w.n_iter, wref.n_iter)
+    with pytest.raises(ValueError):
+        F.solve_tensors_sharded(sh, t2[:2])
+    with pytest.raises(ValueError):
+        F.solve_tensors_sharded(sh, [t2[1], t2[0], t2[2]] if t2[0][0].shape != t2[1][0].shape else [[t.float() for t in t2[0]], t2[1], t2[2]])
+    # ---- page-locked host arrays, asynchronous
+    sh2 = F.FCCQPSharded(60, 38, 12, 38, nb, devices); sh2.set_options(harness_options(F))
+    pin = [torch.from_numpy(np.ascontiguousarray(a)).pin_memory() for a in B.arrays()]
+    z = torch.empty((nb, 60), dtype=torch.float64).pin_memory()
+    sh2.SolveAsync(*(t.numpy() for t in pin))
+    sh2.GetZAsync(z.numpy())
+    sh2.Synchronize()
+    assert np.array_equal(z.numpy(), ref.z)
+    got2 = sh2.GetSolution()
+    assert np.array_equal(got2.z, ref.z) and np.array_equal(got2.n_iter, ref.n_iter)
+    with pytest.raises(ValueError):
+        sh2.SolveAsync(*(a.astype(np.float32) if i == 0 else a for i, a in enumerate(B.arrays())))     # no silent conversion
+    with pytest.raises(ValueError):
+        sh2.SolveAsync(B.Q[:, ::-1, :], *B.arrays()[1:])                                                # no silent copy
+
+
 def test_async_f32_host_solve_equals_the_synchronous_f32_path():
     """fccqp_solve_async_f32: float32 arrays all the way to the device, small vectors widened there --
     bit-identical to fccqp_solve_f32 (host-side widening) on the same arrays."""

@@ -682,6 +682,135 @@ __device__ __forceinline__ double add_lane_halves(const double v) {
   return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
 }
 
+// sum over the lanes of a 16-lane row, in every lane of the row (the first four steps of wave_sum)
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_get<0xB1, 0xf>(v, 0.0);   // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xf>(v, 0.0);   // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xf>(v, 0.0);  // row_half_mirror
+  v += dpp_get<0x140, 0xf>(v, 0.0);  // row_mirror
+  return v;
+}
+
+// ---- presolve by conjugate gradients in the row-split layout (round 5) -------------------------------------------
+// x0 = W^-1 x_c, W = I - rho G (fcc_qp.cpp:159-178 in its Woodbury form; see cg_presolve of the one-wave kernel for why
+// conjugate gradients end in at most n - m + 1 steps here: 29-31 on the large shape's workloads).  The four ADMM waves
+// hold the rows of rho G already (Mrow); what an iteration of the textbook method needs beyond the mat-vec is two
+// inner products, one behind the other -- two more exchange-and-barrier steps when the vectors live one entry per slot.
+// Two things keep an iteration at ONE exchange, ONE barrier and ONE reduction:
+//   * EVERY wave keeps the WHOLE of r and q = W p in the layout the mat-vec reads its operand in (four registers per
+//     lane: the 64 positions of the lane half's two waves, the same in both 16-lane rows of the half).  The one vector
+//     that crosses the waves is w = W r, by the exchange the ADMM loop uses; everything else every wave computes for
+//     itself -- redundantly and, the arithmetic being the same instruction sequence on the same data, bit for bit the
+//     same in all four waves, which therefore also agree on when to stop;
+//   * the Chronopoulos-Gear form of the method: the mat-vec is applied to r, q = W p follows by the recurrence
+//     q = w + beta q, and the two inner products of an iteration, r.r and r.w, are available at the same time --
+//     one 16-lane row of every lane half sums the one, the other row the other (the rows hold the same data), one
+//     row reduction and one addition of the lane halves for both.  (Emulated against the textbook form on the
+//     workloads at rho = 5e-5 .. 1: same iteration counts, x0 within 1e-13 .. 1e-9 of the direct solve alike.)
+// ~0.4 us per iteration against two barriers and an LDS round trip per PANEL for the factorisation of W plus its two
+// sweeps (20.9 + 4.4 us for n = 114).
+// The waves that hold no rows (4 .. 7) wait at the same barriers and read the verdict from an LDS word written in
+// front of each barrier (two slots by barrier parity): 0 go on, 1 done, 2 declined -- the direct path needs them.
+// Declines where the one-wave kernel's does: a diagonal entry of W <= kPresolveMinPivot (published as a NaN in the
+// first exchange, so that all waves see it), p.Wp <= 1e-10 r.r, no convergence to 1e-13 |x_c| in n - m + 10 steps.
+template <class SH, int WV>
+__device__ __forceinline__ bool rs_cg_presolve(lds_f64 *L, const int lane, const bool isvar, const double (&Mrow)[SH::kRsLen],
+                                               const double xc, const double gdiag, double &x0) {
+  constexpr int kCap = (SH::n - SH::m > 0 ? SH::n - SH::m : SH::n) + 10;
+  lds_f64 *const buf = L + SH::kBig + SH::kRsW;               // [2][128] by barrier parity (the ADMM loop's exchange area)
+  lds_i32 *const verdict = (lds_i32 *)(L + SH::kInts) + 8;    // [2] by barrier parity
+  const int half = lane >> 5, slot = lane & 31, pos = 32 * (WV & 3) + slot;
+  int nb = 0;                                                  // barriers passed
+  auto barrier_with = [&](const int code) {
+    if (WV == 0 && lane == 0) verdict[nb & 1] = code;
+    wg_barrier();
+    ++nb;
+  };
+  if constexpr (WV >= 4) {
+    int code;
+    do {
+      wg_barrier();
+      code = verdict[nb & 1];
+      ++nb;
+    } while (code == 0);
+    return code == 1;
+  } else {
+    const unsigned long long odd_rows = __builtin_amdgcn_ballot_w64((lane & 16) != 0);
+    // publish this slot's entry, pass the barrier, fetch the whole vector in the mat-vec's operand layout
+    auto exchange = [&](const double mine, double (&v)[4]) {
+      const int par = nb & 1;
+      buf[128 * par + pos] = mine;
+      barrier_with(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = buf[128 * par + 64 * half + 16 * q + (lane & 15)];
+      lds_fence();
+    };
+    // (a.a, a.b) over all 128 positions: even 16-lane rows sum a.a, odd rows a.b -- both rows of a lane half hold the
+    // same 64 entries --, one row reduction, one addition of the halves; lane 0 then holds the one, lane 16 the other
+    auto two_dots = [&](const double (&va)[4], const double (&vb)[4], double &aa, double &ab) {
+      double d1 = va[0] * va[0], d2 = va[0] * vb[0];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        d1 = fma(va[q], va[q], d1);
+        d2 = fma(va[q], vb[q], d2);
+      }
+      const double t = add_lane_halves(row16_sum(select_lanes(odd_rows, d2, d1)));
+      aa = bcast_lane(t, 0);
+      ab = bcast_lane(t, 16);
+    };
+    auto apply_w = [&](double (&v)[4], const double v_own) {     // (W v)_own = v_own - ((rho G) v)_own
+      double acc = 0.0;
+      // (v may have been written by VALU instructions: two wait states in front of the mat-vec's DPP reads, which the
+      // hazard recogniser does not see inside the asm statement; tests/test_code_objects.py checks the built code)
+      asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+      rs_matvec<SH::kRsOdd>(acc, v, Mrow);
+      return v_own - add_lane_halves(acc);
+    };
+    // r0 = x_c (x = 0); a wave that finds a vanishing diagonal entry of W poisons its share of the first exchange
+    const bool bad_diag = __builtin_amdgcn_ballot_w64(isvar && !(1.0 - gdiag > kPresolveMinPivot)) != 0;
+    double rF[4], wF[4], qF[4];
+    double r_own = xc, x_own = 0.0;
+    exchange(bad_diag ? __builtin_nan("") : xc, rF);
+    double w_own = apply_w(rF, r_own);
+    exchange(w_own, wF);
+    double gamma, delta;
+    two_dots(rF, wF, gamma, delta);
+    const double stop = kCgTolSquared * gamma;
+    int code = 0;                                               // 1 done, 2 declined
+    if (!(gamma > 0.0)) code = (gamma == 0.0) ? 1 : 2;          // x_c == 0: x0 = 0; NaN: decline (uniform: gamma is)
+    else if (!(delta > 1e-10 * gamma)) code = 2;
+    double alpha = gamma * fast_rcp(delta);
+    double p_own = r_own, q_own = w_own;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qF[q] = wF[q];
+#pragma nounroll
+    for (int it = 0; it < kCap && code == 0; ++it) {
+      x_own = fma(alpha, p_own, x_own);
+      r_own = fma(-alpha, q_own, r_own);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rF[q] = fma(-alpha, qF[q], rF[q]);
+      w_own = apply_w(rF, r_own);
+      exchange(w_own, wF);
+      double gamma_new;
+      two_dots(rF, wF, gamma_new, delta);
+      if (!(gamma_new > stop)) { code = (gamma_new <= stop) ? 1 : 2; break; }
+      const double beta = gamma_new * fast_rcp(gamma);
+      const double pwp = delta - beta * gamma_new * fast_rcp(alpha);      // p.Wp of the new direction
+      if (!(pwp > 1e-10 * gamma_new)) { code = 2; break; }                // (also NaN)
+      alpha = gamma_new * fast_rcp(pwp);
+      p_own = fma(beta, p_own, r_own);
+      q_own = fma(beta, q_own, w_own);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) qF[q] = fma(beta, qF[q], wF[q]);
+      gamma = gamma_new;
+    }
+    if (code == 0) code = 2;                                    // the cap
+    barrier_with(code);                                         // the waiting waves learn the verdict here
+    x0 = x_own;
+    return code == 1;
+  }
+}
+
 // ---- the whole solve as seen by wave WV of the workgroup ------------------------------------------------------
 template <class SH, int WV, class TIN>
 __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, lds_f64 *L) {
@@ -739,7 +868,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   constexpr int q0 = (kAdmmWave && !kRS) ? SH::qlo(c) : 0, q1 = (kAdmmWave && !kRS) ? SH::qlo(c + 1) : 1;
   constexpr int col0 = 16 * q0, ncol = kRS ? SH::kRsLen : ((16 * q1 < n) ? 16 * q1 : n) - col0, NQL = kRS ? 4 : q1 - q0;
   double Mrow[ncol];
-  double xc = 0.0, x = 0.0;
+  double xc = 0.0, x = 0.0, gdiag = 0.0;
   long long t4;
   {
     d4 Wt[NW][NW];
@@ -761,6 +890,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     {
       const lds_f64 *img = L + SH::kBig;
       xc = isvar ? rhs[vi] : 0.0;
+      if constexpr (kRS) gdiag = isvar ? img[vi * n + vi] : 0.0;
       if constexpr (kAdmmWave && kRS) {
         // entry e of block k: the variable in slot 16 (k & 1) + e of wave 2 half + (k >> 1) -- its column of this row
         constexpr int LO = SH::kRsOdd;
@@ -783,7 +913,28 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     wg_barrier();                                     // the image is dead: the factor of W goes over it
 
     // ---- presolve (fcc_qp.cpp:159-178; skipped on warm start): x0 = (I - rho G)^-1 x_c, see the one-wave kernel ----
-    if (!a.warm_start) {
+    bool presolved = false;
+    if constexpr (kRS) {
+      // conjugate gradients first (rs_cg_presolve above); the factorisation of W below is the fallback, with its own
+      // singularity rule and the COD hand-off
+      if (!a.warm_start) {
+        flags |= kFlagPresolveRan;
+        if constexpr (kAdmmWave) {
+          presolved = rs_cg_presolve<SH, WV>(L, lane, isvar, Mrow, xc, gdiag, x);
+        } else {
+          double unused_x = 0.0;
+          const double no_rows[SH::kRsLen] = {};
+          presolved = rs_cg_presolve<SH, WV>(L, lane, false, no_rows, 0.0, 0.0, unused_x);
+        }
+        if (presolved) {
+          flags |= kFlagPresolveCg;
+          const long long t5 = wall_clock64();
+          ph_solve = t5 - t4;
+          t4 = t5;
+        }
+      }
+    }
+    if (!a.warm_start && !presolved) {
       flags |= kFlagPresolveRan;
       const long long tw = wall_clock64();
       coop_factor_store<SH, WV>(L, lane, kPresolveMinPivot, Wt);

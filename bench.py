@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--shape", default="walking", choices=["walking", "large"],
                     help="walking = FCCQP(60,38,12,38), the metric's shape; large = FCCQP(114,60,24,66), "
                          "BASELINE configs[3] (secondary: cooperative kernel, eight waves per QP)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fused", "fused_split", "coop"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "fused", "fused_split", "coop", "coop_split"])
     ap.add_argument("--options", default="harness", choices=["harness", "paper"],
                     help="harness: fcc_qp_test.py:78-83 (headline); paper: fccqp.pdf Table 1 (max_iter=15, eps=1e-4)")
     ap.add_argument("--warm", action="store_true",
@@ -79,7 +79,7 @@ def parse_args():
 
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector fp64 (MI355X_MICROARCH.md)
-KERNEL_NAMES = {1: "generic", 2: "fused", 3: "fused_split", 4: "coop"}
+KERNEL_NAMES = {1: "generic", 2: "fused", 3: "fused_split", 4: "coop", 5: "coop_split"}
 
 
 def fused_mfma_count(n, m):
@@ -631,7 +631,7 @@ def main():
     solver.set_options(o)
     solver.set_warm_start(False)
     solver.set_kernel({"auto": F.KERNEL_AUTO, "generic": F.KERNEL_GENERIC, "fused": F.KERNEL_FUSED,
-                       "fused_split": F.KERNEL_FUSED_SPLIT, "coop": F.KERNEL_COOP}[args.kernel])
+                       "fused_split": F.KERNEL_FUSED_SPLIT, "coop": F.KERNEL_COOP, "coop_split": F.KERNEL_COOP_SPLIT}[args.kernel])
     if args.inputs == "f32":   # the problem IS the float-rounded one: oracle and CPU baseline see the same values
         batch = P.Batch(*(a.astype(np.float32).astype(np.float64) for a in batch.arrays()))
     tens = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in batch.arrays()]   # resident in HBM

@@ -25,7 +25,7 @@ except Exception:  # torch is optional plumbing, not a dependency of the solver
 try:
     from .fcc_qp_solver import (  # noqa: F401
         FCCQP, FCCQPBatch, FCCQPBatchSolution, FCCQPDetails, FCCQPError, FCCQPOptions, FCCQPSharded, FCCQPSolution,
-        device_count, kernel_for_shape, KERNEL_AUTO, KERNEL_COOP, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_GENERIC, FLAG_ADMM_NUMERICAL,
+        device_count, kernel_for_shape, KERNEL_AUTO, KERNEL_COOP, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_COOP_SPLIT, KERNEL_GENERIC, FLAG_ADMM_NUMERICAL,
         FLAG_EQ_RESIDUAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_CG, FLAG_PRESOLVE_COD, FLAG_PRESOLVE_NUMERICAL, FLAG_PRESOLVE_RAN)
 except ImportError as exc:  # fail loudly: the HIP extension IS the product
     raise ImportError(

@@ -94,7 +94,8 @@ struct fccqp_solver {
   int *fb_seen_dev = nullptr;
   int fb_full_left = kFbFullFor;
   long long work_stride = 0;
-  // two-launch form of the fused kernel (FCCQP_KERNEL_FUSED_SPLIT): rows of rho G + x_c, allocated on first use
+  // two-launch forms (FCCQP_KERNEL_FUSED_SPLIT, FCCQP_KERNEL_COOP_SPLIT): rows of rho G + x_c, allocated on first use
+  // (a handle's shape has at most one of the two forms in use at a time; the stride is the larger need seen so far)
   double *dsplit = nullptr;
   long long split_stride = 0;
   // -DFCCQP_TICKET_DISPATCH experiment (block_instance, fccqp_device.h): a counter that only grows and the
@@ -170,6 +171,9 @@ size_t n_mu(const fccqp_solver *s) { return (size_t)(s->nc / 3); }
 constexpr size_t kPinnedMirrorBytes = 1u << 20;
 // relative tolerance of the equality-residual self-check (fccqp_check.hip)
 constexpr double kSelfCheckTol = 1e-6;
+// FCCQP_KERNEL_AUTO takes the two-launch form of the cooperative kernel from this many instances per compute unit
+// (the one-launch kernel runs one QP per CU at a time: below two rounds the second launch's ramp is not repaid)
+constexpr int kCoopSplitMinBatchPerCu = 2;
 size_t align256(size_t v) { return (v + 255u) & ~size_t(255); }
 
 int ensure_staging(fccqp_solver *s) {
@@ -274,9 +278,14 @@ int enqueue_impl(fccqp_solver *s, const double *dQ, const double *db, const doub
     return fail(s, FCCQP_ERR_UNSUPPORTED, "no fused kernel for this shape");
   if (kernel == FCCQP_KERNEL_COOP && !can_coop)
     return fail(s, FCCQP_ERR_UNSUPPORTED, "no cooperative kernel for this shape");
+  // (the two-launch form of the cooperative kernel: listed shapes with more than 64 variables)
+  const long long coop_split_need = (s->jit_kind == 0) ? fccqp::coop_split_workspace_doubles(s->n, s->m, s->nc, s->s) : 0;
+  if (kernel == FCCQP_KERNEL_COOP_SPLIT && coop_split_need == 0)
+    return fail(s, FCCQP_ERR_UNSUPPORTED, "no two-launch cooperative kernel for this shape (listed shapes with num_vars > 64)");
   if (kernel == FCCQP_KERNEL_AUTO) {
     if (can_fuse) kernel = FCCQP_KERNEL_FUSED;
-    else if (can_coop) kernel = FCCQP_KERNEL_COOP;
+    else if (can_coop) kernel = (coop_split_need > 0 && s->batch >= kCoopSplitMinBatchPerCu * s->compute_units)
+                                    ? FCCQP_KERNEL_COOP_SPLIT : FCCQP_KERNEL_COOP;
     else kernel = FCCQP_KERNEL_GENERIC;
   }
   const bool want_fused = kernel == FCCQP_KERNEL_FUSED || kernel == FCCQP_KERNEL_FUSED_SPLIT;
@@ -297,6 +306,17 @@ int enqueue_impl(fccqp_solver *s, const double *dQ, const double *db, const doub
     }
     split = waves;
   }
+  // workgroups (QPs) per compute unit in the second launch of the cooperative kernel's two-launch form, 0: one launch
+  int coop_split = 0;
+  if (kernel == FCCQP_KERNEL_COOP_SPLIT) {
+    static const int wgs = [] { const char *e = std::getenv("FCCQP_COOP_SPLIT_WGS"); return (e && e[0] == '2') ? 2 : 3; }();
+    if (!s->dsplit || s->split_stride < coop_split_need) {
+      if (s->dsplit) { HIP_TRY(s, hipStreamSynchronize(stream)); (void)hipFree(s->dsplit); s->dsplit = nullptr; }
+      s->split_stride = coop_split_need;
+      HIP_TRY(s, dmalloc(&s->dsplit, (size_t)s->batch * (size_t)s->split_stride));
+    }
+    coop_split = wgs;
+  }
   // (ordering against the previous solve: order_after_previous, called by the entry points)
   // (defer_fallback is the synchronous small-batch path: its caller waits on the host and records no events)
   s->timed = s->kernel_timing && !defer_fallback;
@@ -305,6 +325,11 @@ int enqueue_impl(fccqp_solver *s, const double *dQ, const double *db, const doub
   if (jit_ready && kernel == s->jit_kind) {
     s->kernel_used = kernel;
     e = fccqp::jit::launch(qa_f32 ? s->jit_f32 : s->jit_f64, a, stream);
+  } else if (kernel == FCCQP_KERNEL_COOP_SPLIT) {
+    s->kernel_used = FCCQP_KERNEL_COOP_SPLIT;
+    fccqp::KernelArgs ac = a;
+    ac.workspace = s->dsplit; ac.workspace_stride = s->split_stride;
+    e = fccqp::launch_coop_split(ac, stream, qa_f32, coop_split);
   } else if (kernel == FCCQP_KERNEL_COOP) {
     s->kernel_used = FCCQP_KERNEL_COOP;
     e = fccqp::launch_coop(a, stream, qa_f32);
@@ -645,7 +670,7 @@ int fccqp_set_warm_start(fccqp_solver *s, int warm_start) {
   return FCCQP_OK;
 }
 int fccqp_set_kernel(fccqp_solver *s, int kernel) {
-  if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_COOP) return FCCQP_ERR_INVALID_ARG;
+  if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_COOP_SPLIT) return FCCQP_ERR_INVALID_ARG;
   s->kernel_request = kernel;
   return FCCQP_OK;
 }

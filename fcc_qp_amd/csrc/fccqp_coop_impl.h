@@ -811,9 +811,235 @@ __device__ __forceinline__ bool rs_cg_presolve(lds_f64 *L, const int lane, const
   }
 }
 
+// ---- the lane's role in the row-split ADMM layout: wave A4 (0 .. 3) of the four that hold rows of rho G ------------
+template <class SH, int A4>
+struct RsLane {
+  using RS = typename SH::RS;
+  int half, slot, pos, var, vi, cidx, ccomp;
+  bool isvar, is_cone;
+  __device__ __forceinline__ explicit RsLane(const int lane) {
+    half = lane >> 5; slot = lane & 31; pos = 32 * A4 + slot;
+    var = RS::slot_variable(A4, slot);
+    isvar = var >= 0;
+    vi = isvar ? var : 0;
+    is_cone = RS::slot_is_cone(A4, slot);
+    cidx = is_cone ? 2 * A4 + (slot >> 4) : 0;
+    ccomp = is_cone ? (slot & 15) : 0;
+  }
+};
+// device stamps of the phases in front of the ADMM loop (100 MHz ticks; phase_ticks of the kernel arguments)
+struct CoopStamps { long long t_begin, ticks, ph_asm, ph_p3, ph_solve, ph_wfac, t4; };
+
+// ---- P4 + P5 in the row-split layout (Shape::kRowSplit, RowSplit): the ADMM iterations (fcc_qp.cpp:74-110), the
+// epilogue metrics (:184-186) and the write-back, as seen by ADMM wave A4.  Called by the whole-solve kernel
+// (coop_wave, SECOND = false) and by the second launch of the two-launch form (coop_admm_kernel, SECOND = true): the
+// same instruction sequence on the same data, hence bit-identical results in both forms.
+// wbuf: the exchange area, [2][128] doubles of w by iteration parity + 64 words for the lanes that carry no exit
+// word; red: [4][4] doubles for the end-of-solve reductions.  Mrow / xc / x: this lane's entries of rho G, x_c and the
+// starting point (x0 of the presolve, or the warm-start state).
+// Per iteration ONE LDS exchange (w by position, double-buffered by iteration parity) and ONE barrier; the per-wave
+// exit words ride on the same barrier.
+template <class SH, int A4, bool SECOND>
+__device__ __forceinline__ void rs_admm_epilogue(const KernelArgs &a, const int inst, lds_f64 *const wbuf, lds_f64 *const red,
+                                                 const int lane, const double (&Mrow)[SH::kRsLen], const double xc, double x,
+                                                 const int flags, const CoopStamps &st) {
+  constexpr int n = SH::n, nc = SH::nc, s0 = SH::s;
+  const RsLane<SH, A4> rl(lane);
+  const int half = rl.half, slot = rl.slot, pos = rl.pos, vi = rl.vi, cidx = rl.cidx, ccomp = rl.ccomp;
+  const bool isvar = rl.isvar, is_cone = rl.is_cone;
+  const double *mup = a.mu + (size_t)inst * (nc / 3);
+  const double *lbp = a.lb + (size_t)inst * n;
+  const double *ubp = a.ub + (size_t)inst * n;
+  double *xs = a.x + (size_t)inst * n;
+  double *mux_s = a.mu_x + (size_t)inst * n;
+  double *mulc_s = a.mu_lc + (size_t)inst * nc;
+  lds_f64 *const w_store[2] = {wbuf + pos, wbuf + 128 + pos};                                       // this slot's w
+  const lds_f64 *const w_fetch[2] = {wbuf + 64 * half + (lane & 15), wbuf + 128 + 64 * half + (lane & 15)};   // + 16 q
+  const double vlb = isvar ? lbp[vi] : -HUGE_VAL;
+  const double vub = isvar ? ubp[vi] : HUGE_VAL;
+  const double vmu = is_cone ? mup[cidx] : 0.0;
+  double mux = 0.0, mulc = 0.0;
+  if (a.warm_start) {
+    mux = isvar ? mux_s[vi] : 0.0;
+    mulc = is_cone ? mulc_s[is_cone ? vi - s0 : 0] : 0.0;
+  }
+  double xbar = x, lcbar = x;                        // :74-75
+  double xr = 0.0, lr = 0.0;
+  const double vkc = cone_lane_constant(vmu, ccomp == 2);
+  const double dir_xy = (ccomp == 2) ? 0.0 : 1.0, dir_z = (ccomp == 2) ? 1.0 : 0.0;
+  const double eps_b = a.eps_bound, eps_f = a.eps_fcone;
+  const double xc_half = half ? 0.0 : xc;            // x_c rides in the lower half's accumulator
+  const int max_iter = a.max_iter;
+  int n_iter = max_iter;                             // :78
+  double Wq[4];
+  wg_barrier();                                      // everyone has x (and is done with the factor of W): the exchange area is free
+  const unsigned long long cone_lanes = __builtin_amdgcn_ballot_w64(is_cone),
+                           flag_lanes = __builtin_amdgcn_ballot_w64(slot == 31),          // where the exit words travel ...
+                           flag_cols = __builtin_amdgcn_ballot_w64((lane & 15) == 15);   // ... and arrive (Wq[1], Wq[3])
+  // (the exit word goes out by a store of its own BEHIND w's -- every lane stores, the lanes of slot 31 to the slot,
+  // the others to a word of their own behind the copies: no EXEC round trip --, so that w does not wait for the
+  // compare-and-mask chain of the exit test)
+  lds_f64 *const f_store[2] = {(slot == 31) ? w_store[0] : wbuf + 256 + lane, (slot == 31) ? w_store[1] : wbuf + 256 + lane};
+  auto publish_w = [&](const int par) {
+    // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82).  Both lane halves hold
+    // the slot's value and store it to the same word.  (A lane without a variable has w == 0.)
+    *w_store[par] = select_lanes(cone_lanes, lcbar - mulc, xbar - mux);
+  };
+  auto publish_flag = [&](const int par, const bool wave_fails) { *f_store[par] = wave_fails ? 1.0 : 0.0; };
+  auto fetch_w = [&](const int par) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Wq[q] = w_fetch[par][16 * q];
+  };
+  if (max_iter > 0) {
+    publish_w(0);
+    lds_fence();
+    publish_flag(0, true);                           // ("not converged": there is no iteration -1 to leave after)
+    wg_barrier();
+    fetch_w(0);
+    lds_fence();
+  }
+  // lane 15 of every 16-lane row of Wq[1] / Wq[3]: slot 31 of the two waves whose columns this lane half multiplies
+  auto everyone_passed = [&]() {
+    return ((__builtin_amdgcn_ballot_w64(Wq[1] != 0.0) | __builtin_amdgcn_ballot_w64(Wq[3] != 0.0)) & flag_cols) == 0;
+  };
+  // One iteration, publishing to / fetching from the copies of parity PAR.  The exit test of the PREVIOUS iteration
+  // (:105-109) is evaluated behind this one's mat-vec: its words arrive with w, and looking at them first would put
+  // their compare-and-branch chain between the loads and the FMAs that wait for the same loads anyway; an iteration
+  // that finds the previous one converged has only computed an accumulator it throws away.  true: leave.
+  auto iteration = [&](auto parc) -> bool {
+    constexpr int PAR = decltype(parc)::value;
+    double acc = xc_half;
+    rs_matvec<SH::kRsOdd>(acc, Wq, Mrow);
+    if (everyone_passed()) return true;
+    x = add_lane_halves(acc);
+    const double xm = x + mulc;
+    {
+      // std::max(std::min(x(i), ub(i)), lb(i)), constraint_utils.cpp:43, as v_min_f64 / v_max_f64 (see the one-wave
+      // kernel; written as asm: the builtins re-canonicalise the loop-invariant bounds in every iteration here)
+      double tt;
+      asm("v_min_f64 %0, %1, %2" : "=v"(tt) : "v"(x + mux), "v"(vub));
+      asm("v_max_f64 %0, %1, %2" : "=v"(xbar) : "v"(tt), "v"(vlb));
+      xr = x - xbar;                    // :95
+      mux += xr;                        // :101
+    }
+    {
+      const double cfx = contact_bcast<0, true>(xm), cfy = contact_bcast<1, true>(xm), cfz = contact_bcast<2, true>(xm);
+      lcbar = project_cone_component_lean(cfx, cfy, cfz, vmu, vkc, xm, dir_xy, dir_z);
+      lr = x - lcbar;                   // :96
+      mulc += lr;                       // :102
+    }
+    publish_w(PAR);
+    lds_fence();
+    // exit test :105-109, this wave's part (a lane without a variable has x_res == 0 and passes)
+    const bool wave_fails = (__builtin_amdgcn_ballot_w64(!(fabs(xr) < eps_b)) |
+                             (cone_lanes & __builtin_amdgcn_ballot_w64(!(fabs(lr) < eps_f)))) != 0;
+    publish_flag(PAR, wave_fails);
+    wg_barrier();
+    fetch_w(PAR);
+    lds_fence();
+    return false;
+  };
+  // two iterations per trip: the parity of the exchange copies is a compile-time constant in each (a wave may be a
+  // whole iteration ahead of the slowest reader of the previous copies, never two)
+  {
+    int iter = 0;
+    bool left = false;
+#pragma nounroll
+    while (iter < max_iter) {
+      if (iteration(int_c<1>{})) { left = true; break; }
+      if (++iter >= max_iter) break;
+      if (iteration(int_c<0>{})) { left = true; break; }
+      ++iter;
+    }
+    // (`iter` iterations ran; the last one's words are in Wq either way)
+    if (max_iter > 0 && (left || everyone_passed())) n_iter = iter - 1;
+  }
+  const long long ph_p4 = wall_clock64() - st.t4;
+
+  // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back; the lower lane half of every ADMM wave reports ---------
+  const bool mine = isvar && half == 0;
+  const double ffy = contact_bcast<1, true>(x), ffz = contact_bcast<2, true>(x);
+  double bv = 0.0, cv = 0.0;
+  if (mine) {
+    const double tt = min2(x, vub);
+    const double pj = max2(tt, vlb);
+    const double dd = x - pj;
+    bv = dd * dd;                                        // constraint_utils.cpp:61-65
+  }
+  if (is_cone && ccomp == 0 && half == 0) {
+    const double v = sqrt(x * x + ffy * ffy) - vmu * ffz;
+    cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
+  }
+  bv = wave_sum(bv);
+  cv = wave_sum(cv);
+  double xrn = 0.0, lrn = 0.0;
+  if (max_iter > 0) {
+    xrn = wave_max(isvar ? fabs(xr) : 0.0);              // :97-98
+    lrn = wave_max(is_cone ? fabs(lr) : 0.0);
+  }
+  if (mine) {
+    xs[vi] = x;
+    mux_s[vi] = mux;                                     // duals are part of the warm-start state (fcc_qp.hpp:149-150)
+  }
+  if (is_cone && half == 0) mulc_s[vi - s0] = mulc;
+  if (lane == 0) {
+    red[4 * (A4) + 0] = xrn; red[4 * (A4) + 1] = lrn; red[4 * (A4) + 2] = bv; red[4 * (A4) + 3] = cv;
+  }
+  wg_barrier();
+  if (A4 == 0 && lane == 0) {
+    double r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
+#pragma unroll
+    for (int hh = 1; hh < 4; ++hh) {
+      r0 = max2(r0, red[4 * hh + 0]); r1 = max2(r1, red[4 * hh + 1]);
+      r2 += red[4 * hh + 2]; r3 += red[4 * hh + 3];
+    }
+    a.n_iter[inst] = n_iter;
+    a.flags[inst] = flags;
+    a.metrics[0 * (size_t)a.batch + inst] = r0;
+    a.metrics[1 * (size_t)a.batch + inst] = r1;
+    a.metrics[2 * (size_t)a.batch + inst] = sqrt(r2);
+    a.metrics[3 * (size_t)a.batch + inst] = r3;
+    if constexpr (SECOND) {
+      // (second launch: the first one left its stamps; slot 5, the instance's total, takes this launch on top)
+      if (a.phase_ticks) {
+        const size_t B = (size_t)a.batch;
+        const long long dt = wall_clock64() - st.t_begin;
+        a.phase_ticks[4 * B + inst] = dt;
+        a.phase_ticks[5 * B + inst] += dt;
+      }
+    } else {
+      a.factor_ticks[inst] = st.ticks;
+      if (a.phase_ticks) {
+        const size_t B = (size_t)a.batch;
+        a.phase_ticks[0 * B + inst] = st.ph_asm;
+        a.phase_ticks[1 * B + inst] = st.ticks;
+        a.phase_ticks[2 * B + inst] = st.ph_solve;
+        a.phase_ticks[3 * B + inst] = st.ph_p3;
+        a.phase_ticks[4 * B + inst] = ph_p4;
+        a.phase_ticks[5 * B + inst] = wall_clock64() - st.t_begin;
+        a.phase_ticks[6 * B + inst] = st.ph_wfac;     // (of slot 1: the factorisation of W alone)
+        a.phase_ticks[7 * B + inst] = st.t_begin;
+      }
+    }
+  }
+}
+
+// ---- the hand-over between the two launches of the two-launch form (row-split shapes) -----------------------------
+// Per instance, in the kernel arguments' workspace (stride a.workspace_stride >= kDoubles): what the four ADMM waves
+// hold in registers when the iterations begin -- entry e of lane l of wave w of rho G's rows at [(w kRsLen + e) 64 + l],
+// x_c at [(4 kRsLen + w) 64 + l]: every wave instruction stores / loads 512 contiguous bytes.  x0 travels in the
+// warm-start state (a.x), which is where a warm start takes x from anyway; flags and stamps in their output arrays.
+template <class SH>
+struct SplitWorkspace {
+  static constexpr int kRowsOff = 0, kXcOff = 4 * SH::kRsLen * 64, kDoubles = kXcOff + 4 * 64;
+};
+
 // ---- the whole solve as seen by wave WV of the workgroup ------------------------------------------------------
-template <class SH, int WV, class TIN>
+// SPLIT = true (row-split shapes only): first launch of the two-launch form -- the wave stops behind the presolve and
+// leaves its rows of rho G and x_c in the workspace (SplitWorkspace), x0 in the warm-start state, for coop_admm_kernel.
+template <class SH, int WV, class TIN, bool SPLIT = false>
 __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, lds_f64 *L) {
+  static_assert(!SPLIT || SH::kRowSplit, "the two-launch form exists for the row-split ADMM layout (num_vars > 64)");
   constexpr int n = SH::n, m = SH::m, nc = SH::nc, s0 = SH::s, N = SH::N, NRB = SH::NRB, NW = SH::NW, RH = SH::RH, CS = SH::CS;
   const int lane = threadIdx.x & 63;
   lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
@@ -846,7 +1072,8 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   const int ccomp = is_cone ? (kRS ? (slot & 15) : (pos & 3)) : 0;
 
   const long long t_begin = wall_clock64();
-  long long ticks = 0, ph_asm = 0, ph_p3 = 0, ph_solve = 0, ph_p4 = 0, ph_wfac = 0;
+  long long ticks = 0, ph_asm = 0, ph_p3 = 0, ph_solve = 0, ph_wfac = 0;
+  [[maybe_unused]] long long ph_p4 = 0;
   int flags = 0;
 
   // [-b; b_eq] (fcc_qp.cpp:149-150) into LDS, by wave 0; flag words cleared
@@ -971,164 +1198,18 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     }
   }
 
-  // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------------------------------
-  // (a wave without a column split is done: s_barrier counts the surviving waves of the workgroup only)
-  if constexpr (!kAdmmWave) return;
-  if constexpr (kRS) {
-    // ---- row-split layout (Shape::kRowSplit, RowSplit): per iteration ONE LDS exchange (w by position, double-
-    // buffered by iteration parity) and ONE barrier; the per-wave exit words ride on the same barrier -------------------
-    // w by position, [2][128] doubles by iteration parity.  Slot 31 of every wave holds no variable (static_assert in
-    // Shape): it carries the wave's exit word -- 1.0 while some residual of the wave is above its eps -- to the other
-    // waves with the same store, barrier and loads that carry w (a word of its own cost a masked store, a 16-byte
-    // load, three ORs and a v_readfirstlane per iteration).
-    lds_f64 *const wbuf = L + SH::kBig + SH::kRsW;
-    lds_f64 *const w_store[2] = {wbuf + pos, wbuf + 128 + pos};                                       // this slot's w
-    const lds_f64 *const w_fetch[2] = {wbuf + 64 * half + (lane & 15), wbuf + 128 + 64 * half + (lane & 15)};   // + 16 q
-    const double vlb = isvar ? lbp[vi] : -HUGE_VAL;
-    const double vub = isvar ? ubp[vi] : HUGE_VAL;
-    const double vmu = is_cone ? mup[cidx] : 0.0;
-    double mux = 0.0, mulc = 0.0;
-    if (a.warm_start) {
-      mux = isvar ? mux_s[vi] : 0.0;
-      mulc = is_cone ? mulc_s[is_cone ? vi - s0 : 0] : 0.0;
-    }
-    double xbar = x, lcbar = x;                        // :74-75
-    double xr = 0.0, lr = 0.0;
-    const double vkc = cone_lane_constant(vmu, ccomp == 2);
-    const double dir_xy = (ccomp == 2) ? 0.0 : 1.0, dir_z = (ccomp == 2) ? 1.0 : 0.0;
-    const double eps_b = a.eps_bound, eps_f = a.eps_fcone;
-    const double xc_half = half ? 0.0 : xc;            // x_c rides in the lower half's accumulator
-    const int max_iter = a.max_iter;
-    int n_iter = max_iter;                             // :78
-    double Wq[4];
-    wg_barrier();                                      // everyone has x (and is done with the factor of W): the exchange area is free
-    const unsigned long long cone_lanes = __builtin_amdgcn_ballot_w64(is_cone),
-                             flag_lanes = __builtin_amdgcn_ballot_w64(slot == 31),          // where the exit words travel ...
-                             flag_cols = __builtin_amdgcn_ballot_w64((lane & 15) == 15);   // ... and arrive (Wq[1], Wq[3])
-    // (the exit word goes out by a store of its own BEHIND w's -- every lane stores, the lanes of slot 31 to the slot,
-    // the others to a word of their own behind the copies: no EXEC round trip --, so that w does not wait for the
-    // compare-and-mask chain of the exit test)
-    lds_f64 *const f_store[2] = {(slot == 31) ? w_store[0] : wbuf + 256 + lane, (slot == 31) ? w_store[1] : wbuf + 256 + lane};
-    auto publish_w = [&](const int par) {
-      // w = x_bar - mu_x, contact segment overwritten by lambda_c_bar - mu_lambda_c (:81-82).  Both lane halves hold
-      // the slot's value and store it to the same word.  (A lane without a variable has w == 0.)
-      *w_store[par] = select_lanes(cone_lanes, lcbar - mulc, xbar - mux);
-    };
-    auto publish_flag = [&](const int par, const bool wave_fails) { *f_store[par] = wave_fails ? 1.0 : 0.0; };
-    auto fetch_w = [&](const int par) {
+  if constexpr (SPLIT) {
+    // ---- hand-over to coop_admm_kernel (SplitWorkspace) ---------------------------------------------------------------
+    if constexpr (kAdmmWave) {
+      using WS = SplitWorkspace<SH>;
+      double *ws = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Wq[q] = w_fetch[par][16 * q];
-    };
-    if (max_iter > 0) {
-      publish_w(0);
-      lds_fence();
-      publish_flag(0, true);                           // ("not converged": there is no iteration -1 to leave after)
-      wg_barrier();
-      fetch_w(0);
-      lds_fence();
+      for (int e = 0; e < SH::kRsLen; ++e) ws[WS::kRowsOff + ((WV & 3) * SH::kRsLen + e) * 64 + lane] = Mrow[e];
+      ws[WS::kXcOff + (WV & 3) * 64 + lane] = xc;
+      if (!a.warm_start && isvar && half == 0) xs[vi] = x;
     }
-    // lane 15 of every 16-lane row of Wq[1] / Wq[3]: slot 31 of the two waves whose columns this lane half multiplies
-    auto everyone_passed = [&]() {
-      return ((__builtin_amdgcn_ballot_w64(Wq[1] != 0.0) | __builtin_amdgcn_ballot_w64(Wq[3] != 0.0)) & flag_cols) == 0;
-    };
-    // One iteration, publishing to / fetching from the copies of parity PAR.  The exit test of the PREVIOUS iteration
-    // (:105-109) is evaluated behind this one's mat-vec: its words arrive with w, and looking at them first would put
-    // their compare-and-branch chain between the loads and the FMAs that wait for the same loads anyway; an iteration
-    // that finds the previous one converged has only computed an accumulator it throws away.  true: leave.
-    auto iteration = [&](auto parc) -> bool {
-      constexpr int PAR = decltype(parc)::value;
-      double acc = xc_half;
-      rs_matvec<SH::kRsOdd>(acc, Wq, Mrow);
-      if (everyone_passed()) return true;
-      x = add_lane_halves(acc);
-      const double xm = x + mulc;
-      {
-        // std::max(std::min(x(i), ub(i)), lb(i)), constraint_utils.cpp:43, as v_min_f64 / v_max_f64 (see the one-wave
-        // kernel; written as asm: the builtins re-canonicalise the loop-invariant bounds in every iteration here)
-        double tt;
-        asm("v_min_f64 %0, %1, %2" : "=v"(tt) : "v"(x + mux), "v"(vub));
-        asm("v_max_f64 %0, %1, %2" : "=v"(xbar) : "v"(tt), "v"(vlb));
-        xr = x - xbar;                    // :95
-        mux += xr;                        // :101
-      }
-      {
-        const double cfx = contact_bcast<0, true>(xm), cfy = contact_bcast<1, true>(xm), cfz = contact_bcast<2, true>(xm);
-        lcbar = project_cone_component_lean(cfx, cfy, cfz, vmu, vkc, xm, dir_xy, dir_z);
-        lr = x - lcbar;                   // :96
-        mulc += lr;                       // :102
-      }
-      publish_w(PAR);
-      lds_fence();
-      // exit test :105-109, this wave's part (a lane without a variable has x_res == 0 and passes)
-      const bool wave_fails = (__builtin_amdgcn_ballot_w64(!(fabs(xr) < eps_b)) |
-                               (cone_lanes & __builtin_amdgcn_ballot_w64(!(fabs(lr) < eps_f)))) != 0;
-      publish_flag(PAR, wave_fails);
-      wg_barrier();
-      fetch_w(PAR);
-      lds_fence();
-      return false;
-    };
-    // two iterations per trip: the parity of the exchange copies is a compile-time constant in each (a wave may be a
-    // whole iteration ahead of the slowest reader of the previous copies, never two)
-    {
-      int iter = 0;
-      bool left = false;
-#pragma nounroll
-      while (iter < max_iter) {
-        if (iteration(int_c<1>{})) { left = true; break; }
-        if (++iter >= max_iter) break;
-        if (iteration(int_c<0>{})) { left = true; break; }
-        ++iter;
-      }
-      // (`iter` iterations ran; the last one's words are in Wq either way)
-      if (max_iter > 0 && (left || everyone_passed())) n_iter = iter - 1;
-    }
-    ph_p4 = wall_clock64() - t4;
-
-    // ---- P5: epilogue (fcc_qp.cpp:184-186) and write-back; the lower lane half of every ADMM wave reports ---------
-    const bool mine = isvar && half == 0;
-    const double ffy = contact_bcast<1, true>(x), ffz = contact_bcast<2, true>(x);
-    double bv = 0.0, cv = 0.0;
-    if (mine) {
-      const double tt = min2(x, vub);
-      const double pj = max2(tt, vlb);
-      const double dd = x - pj;
-      bv = dd * dd;                                        // constraint_utils.cpp:61-65
-    }
-    if (is_cone && ccomp == 0 && half == 0) {
-      const double v = sqrt(x * x + ffy * ffy) - vmu * ffz;
-      cv = (0.0 < v) ? v : 0.0;                            // constraint_utils.cpp:48-59
-    }
-    bv = wave_sum(bv);
-    cv = wave_sum(cv);
-    double xrn = 0.0, lrn = 0.0;
-    if (max_iter > 0) {
-      xrn = wave_max(isvar ? fabs(xr) : 0.0);              // :97-98
-      lrn = wave_max(is_cone ? fabs(lr) : 0.0);
-    }
-    lds_f64 *const red = L + SH::kRed2;
-    if (mine) {
-      xs[vi] = x;
-      mux_s[vi] = mux;                                     // duals are part of the warm-start state (fcc_qp.hpp:149-150)
-    }
-    if (is_cone && half == 0) mulc_s[vi - s0] = mulc;
-    if (lane == 0) {
-      red[4 * (WV & 3) + 0] = xrn; red[4 * (WV & 3) + 1] = lrn; red[4 * (WV & 3) + 2] = bv; red[4 * (WV & 3) + 3] = cv;
-    }
-    wg_barrier();
     if (WV == 0 && lane == 0) {
-      double r0 = red[0], r1 = red[1], r2 = red[2], r3 = red[3];
-#pragma unroll
-      for (int hh = 1; hh < 4; ++hh) {
-        r0 = max2(r0, red[4 * hh + 0]); r1 = max2(r1, red[4 * hh + 1]);
-        r2 += red[4 * hh + 2]; r3 += red[4 * hh + 3];
-      }
-      a.n_iter[inst] = n_iter;
       a.flags[inst] = flags;
-      a.metrics[0 * (size_t)a.batch + inst] = r0;
-      a.metrics[1 * (size_t)a.batch + inst] = r1;
-      a.metrics[2 * (size_t)a.batch + inst] = sqrt(r2);
-      a.metrics[3 * (size_t)a.batch + inst] = r3;
       a.factor_ticks[inst] = ticks;
       if (a.phase_ticks) {
         const size_t B = (size_t)a.batch;
@@ -1136,12 +1217,21 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
         a.phase_ticks[1 * B + inst] = ticks;
         a.phase_ticks[2 * B + inst] = ph_solve;
         a.phase_ticks[3 * B + inst] = ph_p3;
-        a.phase_ticks[4 * B + inst] = ph_p4;
+        a.phase_ticks[4 * B + inst] = 0;
         a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
-        a.phase_ticks[6 * B + inst] = ph_wfac;        // (of slot 1: the factorisation of W alone)
+        a.phase_ticks[6 * B + inst] = ph_wfac;
         a.phase_ticks[7 * B + inst] = t_begin;
       }
     }
+    return;
+  }
+  // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------------------------------
+  // (a wave without a column split is done: s_barrier counts the surviving waves of the workgroup only)
+  if constexpr (!kAdmmWave) return;
+  if constexpr (kRS) {
+    // ---- row-split layout: P4 + P5 (rs_admm_epilogue above) -------------------------------------------------------------
+    const CoopStamps st{t_begin, ticks, ph_asm, ph_p3, ph_solve, ph_wfac, t4};
+    rs_admm_epilogue<SH, (WV & 3), false>(a, inst, L + SH::kBig + SH::kRsW, L + SH::kRed2, lane, Mrow, xc, x, flags, st);
     return;
   } else {
   // ---- n <= 64: the columns of rho G split over CSA waves, partial sums through LDS ------------------------------
@@ -1300,7 +1390,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   }   // (n <= 64: column-split layout)
 }
 
-template <class SH, class TIN>
+template <class SH, class TIN, bool SPLIT = false>
 __global__ __launch_bounds__(kWave * SH::W) void coop_kernel(const KernelArgs a) {
   __shared__ __attribute__((aligned(16))) double lds_raw[SH::kLdsDoubles];
   lds_f64 *const L = (lds_f64 *)lds_raw;
@@ -1308,14 +1398,55 @@ __global__ __launch_bounds__(kWave * SH::W) void coop_kernel(const KernelArgs a)
   if (inst < 0) return;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   switch (wave) {
-    case 0: coop_wave<SH, 0, TIN>(a, inst, L); break;
-    case 1: coop_wave<SH, 1, TIN>(a, inst, L); break;
-    case 2: if constexpr (SH::W > 2) coop_wave<SH, 2, TIN>(a, inst, L); break;
-    case 3: if constexpr (SH::W > 2) coop_wave<SH, 3, TIN>(a, inst, L); break;
-    case 4: if constexpr (SH::W > 4) coop_wave<SH, 4, TIN>(a, inst, L); break;
-    case 5: if constexpr (SH::W > 4) coop_wave<SH, 5, TIN>(a, inst, L); break;
-    case 6: if constexpr (SH::W > 4) coop_wave<SH, 6, TIN>(a, inst, L); break;
-    case 7: if constexpr (SH::W > 4) coop_wave<SH, 7, TIN>(a, inst, L); break;
+    case 0: coop_wave<SH, 0, TIN, SPLIT>(a, inst, L); break;
+    case 1: coop_wave<SH, 1, TIN, SPLIT>(a, inst, L); break;
+    case 2: if constexpr (SH::W > 2) coop_wave<SH, 2, TIN, SPLIT>(a, inst, L); break;
+    case 3: if constexpr (SH::W > 2) coop_wave<SH, 3, TIN, SPLIT>(a, inst, L); break;
+    case 4: if constexpr (SH::W > 4) coop_wave<SH, 4, TIN, SPLIT>(a, inst, L); break;
+    case 5: if constexpr (SH::W > 4) coop_wave<SH, 5, TIN, SPLIT>(a, inst, L); break;
+    case 6: if constexpr (SH::W > 4) coop_wave<SH, 6, TIN, SPLIT>(a, inst, L); break;
+    case 7: if constexpr (SH::W > 4) coop_wave<SH, 7, TIN, SPLIT>(a, inst, L); break;
+    default: break;
+  }
+}
+
+// ---- second launch of the two-launch form: P4 + P5 for one instance per workgroup of FOUR waves, from what
+// coop_kernel<SH, TIN, true> left in the workspace.  The whole-solve kernel holds 8 x 252 registers and 113 KB of LDS
+// per QP -- one QP per CU -- from the first load to the last store, and runs the iterations on one wave per SIMD that
+// spends most of an iteration waiting: for the LDS round trip of w, for the barrier, for its own dependent chain
+// (950 cycles for ~110 VALU instructions).  This kernel needs the rows of rho G (2 kRsLen registers per lane), ~50
+// registers of state and 2.7 KB of LDS, so WGS workgroups -- independent QPs -- share a CU and fill each other's waits.
+// Instances that were handed to the COD pass (fb_list) are skipped; they are solved by the list launch.
+template <class SH, int WGS>
+__global__ __launch_bounds__(kWave * 4, WGS) void coop_admm_kernel(const KernelArgs a) {
+  static_assert(SH::kRowSplit, "row-split ADMM layout");
+  using WS = SplitWorkspace<SH>;
+  __shared__ __attribute__((aligned(16))) double lds_raw[256 + 64 + 16];
+  lds_f64 *const L = (lds_f64 *)lds_raw;
+  const int inst = block_instance(a);
+  if (inst < 0) return;
+  const long long t_begin = wall_clock64();
+  const int flags = a.flags[inst];
+  if (a.fb_list && (flags & kFlagPresolveNumerical)) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const double *ws = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
+  const CoopStamps st{t_begin, 0, 0, 0, 0, 0, t_begin};
+  auto run = [&](auto wc) {
+    constexpr int A4 = decltype(wc)::value;
+    const RsLane<SH, A4> rl(lane);
+    double Mrow[SH::kRsLen];
+#pragma unroll
+    for (int e = 0; e < SH::kRsLen; ++e) Mrow[e] = ws[WS::kRowsOff + (A4 * SH::kRsLen + e) * 64 + lane];
+    const double xc = ws[WS::kXcOff + A4 * 64 + lane];
+    const double x = rl.isvar ? a.x[(size_t)inst * SH::n + rl.vi] : 0.0;
+    rs_admm_epilogue<SH, A4, true>(a, inst, L, L + 256 + 64, lane, Mrow, xc, x, flags, st);
+  };
+  switch (wave) {
+    case 0: run(int_c<0>{}); break;
+    case 1: run(int_c<1>{}); break;
+    case 2: run(int_c<2>{}); break;
+    case 3: run(int_c<3>{}); break;
     default: break;
   }
 }

@@ -199,6 +199,11 @@ hipError_t launch_fused_split(const KernelArgs &a, hipStream_t stream, bool qa_f
 bool coop_supported(int n, int m, int nc, int s);
 int coop_resident_workgroups(int n, int m, int nc, int s, int compute_units);
 hipError_t launch_coop(const KernelArgs &a, hipStream_t stream, bool qa_f32);
+// two-launch form (shapes with num_vars > 64: the row-split ADMM layout): everything up to the presolve at one QP per
+// CU, then the ADMM iterations + epilogue at wgs_per_cu (2 or 3) QPs per CU; a.workspace must hold
+// coop_split_workspace_doubles() doubles per instance (0: the shape has no two-launch form)
+long long coop_split_workspace_doubles(int n, int m, int nc, int s);
+hipError_t launch_coop_split(const KernelArgs &a, hipStream_t stream, bool qa_f32, int wgs_per_cu);
 
 #endif  // !__HIPCC_RTC__
 

@@ -424,6 +424,7 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
   m.attr("KERNEL_FUSED") = (int)FCCQP_KERNEL_FUSED;
   m.attr("KERNEL_FUSED_SPLIT") = (int)FCCQP_KERNEL_FUSED_SPLIT;
   m.attr("KERNEL_COOP") = (int)FCCQP_KERNEL_COOP;
+  m.attr("KERNEL_COOP_SPLIT") = (int)FCCQP_KERNEL_COOP_SPLIT;
   m.attr("FLAG_PRESOLVE_RAN") = (int)FCCQP_FLAG_PRESOLVE_RAN;
   m.attr("FLAG_PRESOLVE_NUMERICAL") = (int)FCCQP_FLAG_PRESOLVE_NUMERICAL;
   m.attr("FLAG_ADMM_NUMERICAL") = (int)FCCQP_FLAG_ADMM_NUMERICAL;

@@ -95,11 +95,20 @@ enum {
                                 bytes per instance).  Bit-identical results; measured 3-4 % faster (round 3; 7 % slower since round 4) at
                                 batch 4096 with 100 iterations, 8 % slower with the paper's 15: AUTO
                                 never picks it                                  */
-  FCCQP_KERNEL_COOP = 4      /* shape-specialised (coop_shapes.def): one workgroup of 2-8 wavefronts per QP,
+  FCCQP_KERNEL_COOP = 4,     /* shape-specialised (coop_shapes.def): one workgroup of 2-8 wavefronts per QP,
                                 the register tiles shared out over the waves.  Shapes with num_vars >= 64
                                 (BASELINE configs[3]: 3x the generic kernel).  AUTO: a listed shape that
                                 has no one-wave kernel (for the walking shape four waves per QP are no
                                 faster than one, even at batch 1)                                     */
+  FCCQP_KERNEL_COOP_SPLIT = 5 /* the cooperative kernel in two launches (listed shapes with num_vars > 64):
+                                everything up to the presolve at one QP per compute unit, then the ADMM
+                                iterations + epilogue at two or three QPs per compute unit, whose waits
+                                (the exchange of w, the barrier) they fill for each other; rho G takes a
+                                round trip through a device workspace of ~1 KB per variable per
+                                instance (allocated on first use).  Bit-identical to FCCQP_KERNEL_COOP.
+                                AUTO takes it for such a shape when the batch is several times the
+                                number of compute units, FCCQP_KERNEL_COOP otherwise (one launch: the
+                                shorter way for a few QPs)                                            */
 };
 
 /* reference: struct FCCQPOptions, src/fcc_qp.hpp:30-35 (same defaults) */

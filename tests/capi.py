@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("FCCQP_LIB_PATH") or os.path.join(ROOT, "fcc_qp_amd", 
 HEADER = os.path.join(ROOT, "include", "fccqp.h")
 
 OK, ERR_INVALID_ARG, ERR_SHAPE, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_FRICTION, ERR_NOT_SOLVED, ERR_UNSUPPORTED = range(9)
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_COOP = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_COOP, KERNEL_COOP_SPLIT = 0, 1, 2, 3, 4, 5
 FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD, FLAG_EQ_RESIDUAL, FLAG_PRESOLVE_CG = 1, 2, 4, 8, 16, 32, 64
 TIMING_NONE, TIMING_DEVICE_EVENTS, TIMING_HOST_CLOCK = 0, 1, 2
 ORIGIN_BUILTIN, ORIGIN_JIT, ORIGIN_GENERIC_ONLY = 0, 1, 2

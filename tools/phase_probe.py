@@ -1,12 +1,12 @@
 """Device phase stamps of one kernel on one shape at one batch size:
-    python tools/phase_probe.py <walking|large> <coop|fused|generic|split> <batch> [W-sat] [max_iter]"""
+    python tools/phase_probe.py <walking|large> <coop|coop_split|fused|generic|split> <batch> [W-sat] [max_iter]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fcc_qp_amd import problems as P
 from tests import capi as C
 shape = {"walking": P.WALKING, "large": P.LARGE}[sys.argv[1]]
-kern = {"coop": C.KERNEL_COOP, "fused": C.KERNEL_FUSED, "generic": C.KERNEL_GENERIC, "split": C.KERNEL_FUSED_SPLIT}[sys.argv[2]]
+kern = {"coop": C.KERNEL_COOP, "fused": C.KERNEL_FUSED, "generic": C.KERNEL_GENERIC, "split": C.KERNEL_FUSED_SPLIT, "coop_split": C.KERNEL_COOP_SPLIT}[sys.argv[2]]
 nb = int(sys.argv[3])
 wl = sys.argv[4] if len(sys.argv) > 4 else "W-sat"
 opts = dict(P.HARNESS_OPTIONS)

@@ -16,48 +16,7 @@ hipError_t launch(const KernelArgs &a, hipStream_t stream, bool qa_f32) {
   else hipLaunchKernelGGL((coop::coop_kernel<SH, double>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
-// the two-launch form (row-split shapes): coop_kernel<SH, TIN, true> up to the presolve, then coop_admm_kernel at
-// `wgs` workgroups (independent QPs) per CU
-template <class SH>
-hipError_t launch_split(const KernelArgs &a, hipStream_t stream, bool qa_f32, int wgs) {
-  if constexpr (SH::kRowSplit) {
-    const dim3 grid(a.batch), block(fused::kWave * SH::W), block2(fused::kWave * 4);
-    if (qa_f32) hipLaunchKernelGGL((coop::coop_kernel<SH, float, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((coop::coop_kernel<SH, double, true>), grid, block, 0, stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (wgs >= 3) hipLaunchKernelGGL((coop::coop_admm_kernel<SH, 3>), grid, block2, 0, stream, a);
-    else hipLaunchKernelGGL((coop::coop_admm_kernel<SH, 2>), grid, block2, 0, stream, a);
-    return hipGetLastError();
-  } else {
-    return hipErrorNotSupported;
-  }
-}
-template <class SH>
-long long split_doubles() {
-  if constexpr (SH::kRowSplit) return coop::SplitWorkspace<SH>::kDoubles;
-  else return 0;
-}
 }  // namespace
-
-// doubles of workspace per instance the two-launch form of this shape needs; 0: the shape has none
-long long coop_split_workspace_doubles(int n, int m, int nc, int s) {
-#define FCCQP_COOP_SHAPE(N_, M_, NC_, S_, W_) \
-  if (matches<coop::Shape<N_, M_, NC_, S_, W_>>(n, m, nc, s)) return split_doubles<coop::Shape<N_, M_, NC_, S_, W_>>();
-#include "coop_shapes.def"
-#undef FCCQP_COOP_SHAPE
-  return 0;
-}
-
-hipError_t launch_coop_split(const KernelArgs &a, hipStream_t stream, bool qa_f32, int wgs_per_cu) {
-  if (a.batch <= 0) return hipSuccess;
-  if (!a.workspace || a.workspace_stride < coop_split_workspace_doubles(a.n, a.m, a.nc, a.s)) return hipErrorInvalidValue;
-#define FCCQP_COOP_SHAPE(N_, M_, NC_, S_, W_) \
-  if (matches<coop::Shape<N_, M_, NC_, S_, W_>>(a.n, a.m, a.nc, a.s)) return launch_split<coop::Shape<N_, M_, NC_, S_, W_>>(a, stream, qa_f32, wgs_per_cu);
-#include "coop_shapes.def"
-#undef FCCQP_COOP_SHAPE
-  return hipErrorNotSupported;
-}
 
 bool coop_supported(int n, int m, int nc, int s) {
 #define FCCQP_COOP_SHAPE(N_, M_, NC_, S_, W_) \

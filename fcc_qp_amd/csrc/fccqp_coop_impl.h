@@ -131,6 +131,9 @@ struct Shape {
   static_assert(4 * kContacts <= kPos, "one quad of lanes per contact");
   using Reduced = ZeroFilledSquare<n>;              // factor of W: zero-filled square, select-free sweeps (fccqp_fused_impl.h)
   static constexpr int ownC(int J) { return J % W; }
+  // (round 5, measured and dropped: pairing the right-hand-side column owners on the SIMDs by their Gram-product load --
+  // (0, 7), (1, 6), (2, 5), (3, 4): nine accumulator tiles per SIMD where the round-robin order has 6 / 8 / 10 / 12 --
+  // shortens the Gram product by 1.3 us per QP and lengthens the factorisation, whose balance it upsets, by 4)
   static constexpr int ownX(int cb) { return cb % W; }
   // column split c of the mat-vec owns the 16-column blocks [qlo(c), qlo(c + 1))
   static constexpr int qlo(int c) { return (NW * c) / CSA; }
@@ -714,11 +717,10 @@ __device__ __forceinline__ double row16_sum(double v) {
 // Declines where the one-wave kernel's does: a diagonal entry of W <= kPresolveMinPivot (published as a NaN in the
 // first exchange, so that all waves see it), p.Wp <= 1e-10 r.r, no convergence to 1e-13 |x_c| in n - m + 10 steps.
 template <class SH, int WV>
-__device__ __forceinline__ bool rs_cg_presolve(lds_f64 *L, const int lane, const bool isvar, const double (&Mrow)[SH::kRsLen],
-                                               const double xc, const double gdiag, double &x0) {
+__device__ __forceinline__ bool rs_cg_presolve(lds_f64 *const buf, lds_i32 *const verdict, const int lane, const bool isvar,
+                                               const double (&Mrow)[SH::kRsLen], const double xc, const double gdiag, double &x0) {
+  // buf: [2][128] doubles by barrier parity (the ADMM loop's exchange area); verdict: [2] words by barrier parity
   constexpr int kCap = (SH::n - SH::m > 0 ? SH::n - SH::m : SH::n) + 10;
-  lds_f64 *const buf = L + SH::kBig + SH::kRsW;               // [2][128] by barrier parity (the ADMM loop's exchange area)
-  lds_i32 *const verdict = (lds_i32 *)(L + SH::kInts) + 8;    // [2] by barrier parity
   const int half = lane >> 5, slot = lane & 31, pos = 32 * (WV & 3) + slot;
   int nb = 0;                                                  // barriers passed
   auto barrier_with = [&](const int code) {
@@ -1003,9 +1005,9 @@ __device__ __forceinline__ void rs_admm_epilogue(const KernelArgs &a, const int 
       // (second launch: the first one left its stamps; slot 5, the instance's total, takes this launch on top)
       if (a.phase_ticks) {
         const size_t B = (size_t)a.batch;
-        const long long dt = wall_clock64() - st.t_begin;
-        a.phase_ticks[4 * B + inst] = dt;
-        a.phase_ticks[5 * B + inst] += dt;
+        a.phase_ticks[2 * B + inst] = st.ph_solve;
+        a.phase_ticks[4 * B + inst] = ph_p4;
+        a.phase_ticks[5 * B + inst] += wall_clock64() - st.t_begin;
       }
     } else {
       a.factor_ticks[inst] = st.ticks;
@@ -1024,19 +1026,23 @@ __device__ __forceinline__ void rs_admm_epilogue(const KernelArgs &a, const int 
   }
 }
 
-// ---- the hand-over between the two launches of the two-launch form (row-split shapes) -----------------------------
+// ---- the hand-over between the launches of the two-launch form (row-split shapes) --------------------------------
 // Per instance, in the kernel arguments' workspace (stride a.workspace_stride >= kDoubles): what the four ADMM waves
-// hold in registers when the iterations begin -- entry e of lane l of wave w of rho G's rows at [(w kRsLen + e) 64 + l],
-// x_c at [(4 kRsLen + w) 64 + l]: every wave instruction stores / loads 512 contiguous bytes.  x0 travels in the
-// warm-start state (a.x), which is where a warm start takes x from anyway; flags and stamps in their output arrays.
+// hold in registers behind the Gram product -- entry e of lane l of wave w of rho G's rows at [(w kRsLen + e) 64 + l],
+// x_c at [(4 kRsLen + w) 64 + l], the diagonal entry of rho G of the lane's variable at [(4 kRsLen + 4 + w) 64 + l]:
+// every wave instruction stores / loads 512 contiguous bytes.  Flags and stamps travel in their output arrays.
 template <class SH>
 struct SplitWorkspace {
-  static constexpr int kRowsOff = 0, kXcOff = 4 * SH::kRsLen * 64, kDoubles = kXcOff + 4 * 64;
+  static constexpr int kRowsOff = 0, kXcOff = 4 * SH::kRsLen * 64, kGdOff = kXcOff + 4 * 64, kDoubles = kGdOff + 4 * 64;
 };
+// internal flag bit between the launches: conjugate gradients declined this instance in the second launch; the third
+// launch (the whole-solve kernel behind a gate) solves it again from the start and leaves the public flags only
+constexpr int kFlagRedo = 1 << 30;
 
 // ---- the whole solve as seen by wave WV of the workgroup ------------------------------------------------------
-// SPLIT = true (row-split shapes only): first launch of the two-launch form -- the wave stops behind the presolve and
-// leaves its rows of rho G and x_c in the workspace (SplitWorkspace), x0 in the warm-start state, for coop_admm_kernel.
+// SPLIT = true (row-split shapes only): first launch of the two-launch form -- the wave stops behind the Gram product
+// and leaves its rows of rho G, x_c and the diagonal of rho G in the workspace (SplitWorkspace) for coop_admm_kernel,
+// which runs the presolve by conjugate gradients, the iterations and the epilogue.
 template <class SH, int WV, class TIN, bool SPLIT = false>
 __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, lds_f64 *L) {
   static_assert(!SPLIT || SH::kRowSplit, "the two-launch form exists for the row-split ADMM layout (num_vars > 64)");
@@ -1136,6 +1142,33 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
         for (int j = 0; j < ncol; ++j) Mrow[j] = isvar ? img[vi * n + col0 + j] : 0.0;
       }
     }
+    if constexpr (SPLIT) {
+      // ---- hand-over to coop_admm_kernel (SplitWorkspace) -------------------------------------------------------------
+      if constexpr (kAdmmWave) {
+        using WS = SplitWorkspace<SH>;
+        double *ws = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
+#pragma unroll
+        for (int e = 0; e < SH::kRsLen; ++e) ws[WS::kRowsOff + ((WV & 3) * SH::kRsLen + e) * 64 + lane] = Mrow[e];
+        ws[WS::kXcOff + (WV & 3) * 64 + lane] = xc;
+        ws[WS::kGdOff + (WV & 3) * 64 + lane] = gdiag;
+      }
+      if (WV == 0 && lane == 0) {
+        a.flags[inst] = flags;
+        a.factor_ticks[inst] = ticks;
+        if (a.phase_ticks) {
+          const size_t B = (size_t)a.batch;
+          a.phase_ticks[0 * B + inst] = ph_asm;
+          a.phase_ticks[1 * B + inst] = ticks;
+          a.phase_ticks[2 * B + inst] = 0;
+          a.phase_ticks[3 * B + inst] = ph_p3;
+          a.phase_ticks[4 * B + inst] = 0;
+          a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
+          a.phase_ticks[6 * B + inst] = 0;
+          a.phase_ticks[7 * B + inst] = t_begin;
+        }
+      }
+      return;
+    }
     if (a.warm_start) x = isvar ? xs[vi] : 0.0;       // fcc_qp.cpp:136-139
     wg_barrier();                                     // the image is dead: the factor of W goes over it
 
@@ -1147,11 +1180,11 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       if (!a.warm_start) {
         flags |= kFlagPresolveRan;
         if constexpr (kAdmmWave) {
-          presolved = rs_cg_presolve<SH, WV>(L, lane, isvar, Mrow, xc, gdiag, x);
+          presolved = rs_cg_presolve<SH, WV>(L + SH::kBig + SH::kRsW, (lds_i32 *)(L + SH::kInts) + 8, lane, isvar, Mrow, xc, gdiag, x);
         } else {
           double unused_x = 0.0;
           const double no_rows[SH::kRsLen] = {};
-          presolved = rs_cg_presolve<SH, WV>(L, lane, false, no_rows, 0.0, 0.0, unused_x);
+          presolved = rs_cg_presolve<SH, WV>(L + SH::kBig + SH::kRsW, (lds_i32 *)(L + SH::kInts) + 8, lane, false, no_rows, 0.0, 0.0, unused_x);
         }
         if (presolved) {
           flags |= kFlagPresolveCg;
@@ -1198,33 +1231,6 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     }
   }
 
-  if constexpr (SPLIT) {
-    // ---- hand-over to coop_admm_kernel (SplitWorkspace) ---------------------------------------------------------------
-    if constexpr (kAdmmWave) {
-      using WS = SplitWorkspace<SH>;
-      double *ws = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
-#pragma unroll
-      for (int e = 0; e < SH::kRsLen; ++e) ws[WS::kRowsOff + ((WV & 3) * SH::kRsLen + e) * 64 + lane] = Mrow[e];
-      ws[WS::kXcOff + (WV & 3) * 64 + lane] = xc;
-      if (!a.warm_start && isvar && half == 0) xs[vi] = x;
-    }
-    if (WV == 0 && lane == 0) {
-      a.flags[inst] = flags;
-      a.factor_ticks[inst] = ticks;
-      if (a.phase_ticks) {
-        const size_t B = (size_t)a.batch;
-        a.phase_ticks[0 * B + inst] = ph_asm;
-        a.phase_ticks[1 * B + inst] = ticks;
-        a.phase_ticks[2 * B + inst] = ph_solve;
-        a.phase_ticks[3 * B + inst] = ph_p3;
-        a.phase_ticks[4 * B + inst] = 0;
-        a.phase_ticks[5 * B + inst] = wall_clock64() - t_begin;
-        a.phase_ticks[6 * B + inst] = ph_wfac;
-        a.phase_ticks[7 * B + inst] = t_begin;
-      }
-    }
-    return;
-  }
   // ---- P4: ADMM iterations (fcc_qp.cpp:74-110) ---------------------------------------------------------------------
   // (a wave without a column split is done: s_barrier counts the surviving waves of the workgroup only)
   if constexpr (!kAdmmWave) return;
@@ -1390,12 +1396,20 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   }   // (n <= 64: column-split layout)
 }
 
-template <class SH, class TIN, bool SPLIT = false>
+// MODE 0: the whole solve in one launch.  MODE 1: first launch of the two-launch form (up to the Gram product).
+// MODE 2: third launch of the two-launch form -- the whole solve again, for the instances the second launch marked
+// (kFlagRedo: conjugate gradients declined; the direct factorisation of W, its singularity rule and the COD hand-off
+// live in this kernel); every other workgroup leaves at once.
+template <class SH, class TIN, int MODE = 0>
 __global__ __launch_bounds__(kWave * SH::W) void coop_kernel(const KernelArgs a) {
   __shared__ __attribute__((aligned(16))) double lds_raw[SH::kLdsDoubles];
   lds_f64 *const L = (lds_f64 *)lds_raw;
   const int inst = block_instance(a);
   if (inst < 0) return;
+  if constexpr (MODE == 2) {
+    if (!(a.flags[inst] & kFlagRedo)) return;
+  }
+  constexpr bool SPLIT = MODE == 1;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   switch (wave) {
     case 0: coop_wave<SH, 0, TIN, SPLIT>(a, inst, L); break;
@@ -1410,36 +1424,59 @@ __global__ __launch_bounds__(kWave * SH::W) void coop_kernel(const KernelArgs a)
   }
 }
 
-// ---- second launch of the two-launch form: P4 + P5 for one instance per workgroup of FOUR waves, from what
-// coop_kernel<SH, TIN, true> left in the workspace.  The whole-solve kernel holds 8 x 252 registers and 113 KB of LDS
-// per QP -- one QP per CU -- from the first load to the last store, and runs the iterations on one wave per SIMD that
-// spends most of an iteration waiting: for the LDS round trip of w, for the barrier, for its own dependent chain
-// (950 cycles for ~110 VALU instructions).  This kernel needs the rows of rho G (2 kRsLen registers per lane), ~50
-// registers of state and 2.7 KB of LDS, so WGS workgroups -- independent QPs -- share a CU and fill each other's waits.
-// Instances that were handed to the COD pass (fb_list) are skipped; they are solved by the list launch.
+// ---- second launch of the two-launch form: presolve by conjugate gradients, P4 and P5 for one instance per workgroup
+// of FOUR waves, from what coop_kernel<SH, TIN, 1> left in the workspace.  The whole-solve kernel holds 8 x 252
+// registers and 145 KB of LDS per QP -- one QP per CU -- from the first load to the last store, and runs the conjugate
+// gradients and the iterations on one wave per SIMD that spends most of an iteration waiting: for the LDS round trip of
+// w, for the barrier, for its own dependent chain (950 cycles for ~110 VALU instructions; SQ counters of that kernel:
+// 54 % of the wave time parked at an s_waitcnt, profiles/r05_large_sq_counters.json).  This kernel needs the rows of
+// rho G (2 kRsLen registers per lane), ~50 registers of state and 2.7 KB of LDS, so WGS workgroups -- independent QPs --
+// share a CU and fill each other's waits.
+// An instance whose conjugate gradients decline (rs_cg_presolve: W = I - rho G singular or ill-conditioned) is marked
+// kFlagRedo and left alone; coop_kernel<SH, TIN, 2> solves it from the start.
 template <class SH, int WGS>
 __global__ __launch_bounds__(kWave * 4, WGS) void coop_admm_kernel(const KernelArgs a) {
   static_assert(SH::kRowSplit, "row-split ADMM layout");
   using WS = SplitWorkspace<SH>;
-  __shared__ __attribute__((aligned(16))) double lds_raw[256 + 64 + 16];
+  __shared__ __attribute__((aligned(16))) double lds_raw[256 + 64 + 16 + 2];
   lds_f64 *const L = (lds_f64 *)lds_raw;
   const int inst = block_instance(a);
   if (inst < 0) return;
   const long long t_begin = wall_clock64();
-  const int flags = a.flags[inst];
-  if (a.fb_list && (flags & kFlagPresolveNumerical)) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const double *ws = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
-  const CoopStamps st{t_begin, 0, 0, 0, 0, 0, t_begin};
   auto run = [&](auto wc) {
     constexpr int A4 = decltype(wc)::value;
     const RsLane<SH, A4> rl(lane);
+    int flags = a.flags[inst];
     double Mrow[SH::kRsLen];
 #pragma unroll
     for (int e = 0; e < SH::kRsLen; ++e) Mrow[e] = ws[WS::kRowsOff + (A4 * SH::kRsLen + e) * 64 + lane];
     const double xc = ws[WS::kXcOff + A4 * 64 + lane];
-    const double x = rl.isvar ? a.x[(size_t)inst * SH::n + rl.vi] : 0.0;
+    double x = 0.0;
+    long long ph_solve = 0, t4 = t_begin;
+    if (a.phase_ticks) {
+      // (stamp of the hand-over's arrival: slot 6 of the phase stamps, which the first launch leaves at zero)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (A4 == 0 && lane == 0) a.phase_ticks[6 * (size_t)a.batch + inst] = wall_clock64() - t_begin;
+    }
+    if (a.warm_start) {
+      x = rl.isvar ? a.x[(size_t)inst * SH::n + rl.vi] : 0.0;       // fcc_qp.cpp:136-139
+    } else {
+      // presolve (fcc_qp.cpp:159-178): x0 = (I - rho G)^-1 x_c by conjugate gradients
+      const double gdiag = ws[WS::kGdOff + A4 * 64 + lane];
+      flags |= kFlagPresolveRan;
+      const bool presolved = rs_cg_presolve<SH, A4>(L, (lds_i32 *)(L + 256 + 64 + 16), lane, rl.isvar, Mrow, xc, gdiag, x);
+      if (!presolved) {
+        if (A4 == 0 && lane == 0) a.flags[inst] = kFlagRedo;
+        return;
+      }
+      flags |= kFlagPresolveCg;
+      t4 = wall_clock64();
+      ph_solve = t4 - t_begin;
+    }
+    const CoopStamps st{t_begin, 0, 0, 0, ph_solve, 0, t4};
     rs_admm_epilogue<SH, A4, true>(a, inst, L, L + 256 + 64, lane, Mrow, xc, x, flags, st);
   };
   switch (wave) {

@@ -53,8 +53,26 @@ def test_option_sets_random_population(oracle, options):
     one = gpu(LARGE, options, B, CAPI.KERNEL_COOP, warm_steps=1)
     two = gpu(LARGE, options, B, CAPI.KERNEL_COOP_SPLIT, warm_steps=1)
     assert_same_bits(one, two, str(options))
+    assert all(x.flags & CAPI.FLAG_PRESOLVE_CG for x in two[0][2])
     z_ref, it_ref, _ = oracle_batch(oracle, LARGE, options, B)
     assert_parity(two[0][0], two[0][1], z_ref, it_ref, tol=Z_TOL_TIGHT, what=f"coop_split {options}")
+
+
+@pytest.mark.parametrize("rho", [100.0, 1e4])
+def test_declined_conjugate_gradients_go_through_the_third_launch(rho):
+    """cond(W) ~ rho / lambda_min of the reduced Hessian: at rho = 100 and beyond conjugate gradients do not converge in
+    n - m + 10 steps on the OSC workloads and decline in the second launch; the third launch (the whole-solve kernel behind
+    its gate) takes the direct factorisation of W for exactly those instances.  (No oracle here: this is beyond the
+    Woodbury presolve's own accuracy envelope, tests/test_gpu_parity.py; what is checked is that the two forms agree.)"""
+    options = dict(max_iter=20, rho=rho, eps_fcone=1e-6, eps_bound=1e-6)
+    B = P.workload("W-sat", 36, P.LARGE)
+    one = gpu(LARGE, options, B, CAPI.KERNEL_COOP, warm_steps=1)
+    two = gpu(LARGE, options, B, CAPI.KERNEL_COOP_SPLIT, warm_steps=1)
+    assert_same_bits(one, two, f"rho={rho}")
+    cg = [bool(x.flags & CAPI.FLAG_PRESOLVE_CG) for x in two[0][2]]
+    assert not all(cg), "expected conjugate gradients to decline on some instance"
+    assert all(x.flags & CAPI.FLAG_PRESOLVE_RAN for x in two[0][2])
+    assert np.all(np.isfinite(two[0][0]))
 
 
 def test_fp32_storage_inputs():

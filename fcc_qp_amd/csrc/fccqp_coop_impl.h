@@ -268,13 +268,29 @@ __device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &
 }
 
 // ---- P1: K_rho = U^T D U with the forward solve of [E | r] fused in, tile columns shared out over the waves ----
-template <class SH, int WV>
+// FUSE: the Gram product G = Y^T D^-1 Y is a sum over the row blocks of Y, and row block P of Y is final the moment
+// panel P has solved it -- so its term is added right there: the owners publish Y_p beside V_p (same barrier), and every
+// wave adds (Y_p[.][I])^T D_p^-1 Y_p[.][J] to the accumulator tiles Gt[I][J] of its own columns J behind the trailing
+// update.  Against a Gram product of its own behind the factorisation (coop_gram: publish + barrier per row block)
+// eleven barriers and their LDS round trips go, the matrix-core work fills waits of the panels, and a row block of Y
+// is dead as soon as its panel ends.
+template <class SH, int WV, bool FUSE>
 __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, d4 (&C)[SH::NRB][SH::NRB],
-                                                    d4 (&X)[SH::NRB][SH::NXB]) {
+                                                    d4 (&X)[SH::NRB][SH::NXB], d4 (&Gt)[SH::NW][SH::NXB]) {
   constexpr int N = SH::N, n = SH::n, NRB = SH::NRB, NXB = SH::NXB, cbd = SH::cbd;
   const int col = lane & 15, grp = lane >> 4;
   lds_f64 *const Sinv = L + SH::kSinv, *const Srcp = L + SH::kSrcp, *const rhs = L + SH::kRhs;
   lds_f64 *const Vbuf = L + SH::kBig;
+  lds_f64 *const Yfbuf = L + SH::kBig + SH::kVbufLen;          // FUSE: Y_p of two panels, behind the V tiles
+  static_assert(!FUSE || SH::kVbufLen + SH::kYbufLen <= SH::kBigLen, "room for the published Y tiles");
+  constexpr int IMAX = SH::NW - 1;                             // last row block of G that is needed
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int J = 0; J <= cbd; ++J)
+      if (SH::ownX(J) == WV)
+#pragma unroll
+        for (int I = 0; I <= ((J < IMAX) ? J : IMAX); ++I) Gt[I][J] = d4{0.0, 0.0, 0.0, 0.0};
+  }
   lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
   auto zero_tile = [](int K, int cb) { return K < cb && cb != cbd; };
   auto kfirst = [](int cb) { return (cb == cbd) ? 0 : cb; };
@@ -298,6 +314,31 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     const bool bad = diag_tile<kValid, true, false>(L, lane, C[Pn][Pn], T, rmine, 0.0, Pn & 1);
     if (lane < 16) L[SH::kRcp + 16 * Pn + col] = rmine;
     if (bad && lane == 0) iflags[0] = 1;
+  };
+  // FUSE: the term of row block P of Y in the own accumulator tiles (nrv: -1/d of the panel's rows)
+  auto gram_step = [&](auto pc, const double (&nrv)[4]) {
+    constexpr int P = decltype(pc)::value;
+#pragma unroll
+    for (int I = 0; I <= IMAX; ++I) {
+      if (!zero_tile(P, I)) {
+        bool any = false;
+#pragma unroll
+        for (int J = I; J <= cbd; ++J) any = any || (SH::ownX(J) == WV && !zero_tile(P, J));
+        if (any) {
+          const d4 y = tile_fetch(Yfbuf + ((P & 1) * NXB + I) * SH::kTile, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (16 * P + 4 * r < N) {
+              const double aop = y[r] * -nrv[r];
+#pragma unroll
+              for (int J = I; J <= cbd; ++J)
+                if (SH::ownX(J) == WV && !zero_tile(P, J))
+                  Gt[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[P][J][r], Gt[I][J], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
   };
   if constexpr (SH::ownC(0) == WV) factor_diag(int_c<0>{});
   wg_barrier();
@@ -331,7 +372,14 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
         for (int r = 0; r < 4; ++r)
           if (16 * P + 4 * r < N) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], X[P][cb][r], t, 0, 0, 0);
         X[P][cb] = t;
+        if constexpr (FUSE) {
+          if (cb <= cbd) tile_publish(Yfbuf + ((P & 1) * NXB + cb) * SH::kTile, lane, t);
+        }
       }
+    }
+    if constexpr (P + 1 == NRB && FUSE) {
+      wg_barrier();
+      gram_step(pc, nrv);
     }
     if constexpr (P + 1 < NRB) {
       wg_barrier();
@@ -378,6 +426,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
           }
         }
       }
+      if constexpr (FUSE) gram_step(pc, nrv);
       wg_barrier();      // the next diagonal tile is published; every wave is done with the V tiles of panel P
     }
   });
@@ -385,15 +434,16 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
 
 // ---- P3: rho G and x_c as the Gram product Y^T D^-1 Y; own tile columns J (the owner of X column J) ---------------
 // Leaves rho G in the LDS image (row-major n x n), x_c in xcv[0..n), and the own upper tiles of W = I - rho G in Wt.
-template <class SH, int WV>
+// FUSED: the accumulator tiles Gt arrive complete from coop_factor_forward<.., true>; only the output half runs.
+template <class SH, int WV, bool FUSED>
 __device__ __forceinline__ void coop_gram(lds_f64 *L, const int lane, const double rho, const d4 (&X)[SH::NRB][SH::NXB],
-                                          d4 (&Wt)[SH::NW][SH::NW]) {
+                                          d4 (&Gt)[SH::NW][SH::NXB], d4 (&Wt)[SH::NW][SH::NW]) {
   constexpr int N = SH::N, n = SH::n, NRB = SH::NRB, NXB = SH::NXB, NW = SH::NW, cbd = SH::cbd;
   const int col = lane & 15, grp = lane >> 4;
   lds_f64 *const Ybuf = L + SH::kBig, *const img = L + SH::kBig, *const xcv = L + SH::kRhs;
   auto kmin = [](int cb) { return (cb == cbd) ? 0 : cb; };
   constexpr int IMAX = NW - 1;                      // last row block of G that is needed
-  d4 Gt[NW][NXB];
+  if constexpr (!FUSED) {
 #pragma unroll
   for (int J = 0; J <= cbd; ++J)
     if (SH::ownX(J) == WV)
@@ -432,6 +482,7 @@ __device__ __forceinline__ void coop_gram(lds_f64 *L, const int lane, const doub
       }
     }
   });
+  }   // (!FUSED)
   wg_barrier();      // every wave is done with the published Y tiles: the image goes over them
 #pragma unroll
   for (int J = 0; J <= cbd; ++J) {
@@ -1066,6 +1117,11 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   // own 32 slots of variables each (lane & 31; both lane halves hold the slot's variable), the lane half picks the
   // column half of rho G.
   constexpr bool kRS = SH::kRowSplit;
+#ifdef FCCQP_COOP_FUSE_GRAM_ALWAYS
+  constexpr bool kFuseGram = true;
+#else
+  constexpr bool kFuseGram = SPLIT;                 // (Gram product inside the factorisation's panels: first launch of the two-launch form)
+#endif
   using RS = typename SH::RS;
   constexpr int h = kRS ? 0 : WV % RH, c = kRS ? 0 : WV / RH;
   const int half = lane >> 5, slot = lane & 31;
@@ -1111,10 +1167,11 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       const long long t0 = wall_clock64();
       ph_asm = t0 - t_begin;
       wg_barrier();                                   // rhs and the cleared flags are visible
-      coop_factor_forward<SH, WV>(L, lane, C, X);
+      d4 Gt[NW][SH::NXB];
+      coop_factor_forward<SH, WV, kFuseGram>(L, lane, C, X, Gt);
       const long long t3 = wall_clock64();
       ticks = t3 - t0;
-      coop_gram<SH, WV>(L, lane, a.rho, X, Wt);
+      coop_gram<SH, WV, kFuseGram>(L, lane, a.rho, X, Gt, Wt);
       t4 = wall_clock64();
       ph_p3 = t4 - t3;
     }

@@ -332,8 +332,10 @@ def secondary_measurements(F, P, O, torch, dev, dev_index, log, steps=20, warmup
     run("fused_split", P.WALKING, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_FUSED_SPLIT)
     run("fused_split_w_mix", P.WALKING, "W-mix", P.HARNESS_OPTIONS, kernel=F.KERNEL_FUSED_SPLIT)
     # BASELINE configs[3]: 36-DoF / 8-contact shape -- cooperative kernel (eight waves per QP share the register
-    # tiles), and the generic kernel it replaced for this shape
+    # tiles; at this batch size AUTO takes its two-launch form: factorisation + Gram product at one QP per CU, conjugate
+    # gradients + ADMM iterations at three), the same in one launch, and the generic kernel it replaced for this shape
     run("large_shape", P.LARGE, "W-sat", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
+    run("large_shape_one_launch", P.LARGE, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_COOP, distinct=32, parity_k=16, steps=8, warmup=2)
     run("large_shape_generic", P.LARGE, "W-sat", P.HARNESS_OPTIONS, kernel=F.KERNEL_GENERIC, distinct=32, parity_k=16, steps=4, warmup=1)
     run("large_shape_w_mix", P.LARGE, "W-mix", P.HARNESS_OPTIONS, distinct=32, parity_k=16, steps=8, warmup=2)
     # a humanoid-sized shape no specialised kernel is compiled for: 44 DoF, 38 inputs, 12 contacts -> FCCQP(148, 74, 36, 82),

@@ -610,13 +610,16 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
       const bool qf = fccqp::jit::qualifies(fccqp::jit::kFused, num_vars, num_equality_constraints, nc, lambda_c_start, nullptr);
       const bool qc = fccqp::jit::qualifies(fccqp::jit::kCoop, num_vars, num_equality_constraints, nc, lambda_c_start, nullptr);
       const bool have_f = qf && fccqp::jit::acquire(fccqp::jit::kFused, num_vars, num_equality_constraints, nc, lambda_c_start, false, &kf, &why_f);
+      bool have_c = false;
       if (have_f && kf.scratch_bytes == 0) {
         s->jit_kind = FCCQP_KERNEL_FUSED; s->jit_f64 = kf;
-      } else if (qc && fccqp::jit::acquire(fccqp::jit::kCoop, num_vars, num_equality_constraints, nc, lambda_c_start, false, &kc, &why_c) &&
+      } else if ((have_c = qc && fccqp::jit::acquire(fccqp::jit::kCoop, num_vars, num_equality_constraints, nc, lambda_c_start, false, &kc, &why_c)) &&
                  kc.scratch_bytes == 0) {
         s->jit_kind = FCCQP_KERNEL_COOP; s->jit_f64 = kc;
       } else if (have_f) {
         s->jit_kind = FCCQP_KERNEL_FUSED; s->jit_f64 = kf;       // (spills registers; still well ahead of the generic kernel)
+      } else if (have_c) {
+        s->jit_kind = FCCQP_KERNEL_COOP; s->jit_f64 = kc;        // (likewise: a few spilled registers against 3x the time)
       } else if (qf || qc) {
         s->err = "no run-time compiled kernel for this shape (" + (why_f.empty() ? why_c : why_f) + "): generic kernel";
       }

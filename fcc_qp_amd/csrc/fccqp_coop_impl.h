@@ -17,17 +17,26 @@
 //       the MFMA A operand of k-step r) | barrier | every wave updates its own columns,
 //       C_ij -= V_pi^T D^-1 V_pj, X_i -= V_pi^T D^-1 Y_p, with V_pi read from LDS.  Two barriers per panel, the
 //       published tiles double-buffered by panel parity.
-//   P3  Gram product G = Y^T D^-1 Y by row blocks K of Y: publish Y[K][.] | barrier | accumulate the own tile
-//       columns.  rho G goes through an n x n LDS image to the ADMM layout, W = I - rho G stays in registers.
-//   Pw  presolve x0 = W^-1 x_c (Woodbury, as in the one-wave kernel): W factorised by the same panel scheme, its
-//       factor written packed to LDS, the two triangular sweeps by wave 0 (two rows per lane for n > 64).
+//   P3  Gram product G = Y^T D^-1 Y: a sum over the row blocks of Y, and row block p is final when panel p has solved
+//       it -- its term is added inside panel p (Y_p published beside V_p, same barriers; round 5).  rho G goes through
+//       an n x n LDS image to the ADMM layout, W = I - rho G stays in registers.
+//   Pw  presolve x0 = W^-1 x_c (Woodbury, as in the one-wave kernel).  num_vars > 64: by conjugate gradients on the rows
+//       of rho G the ADMM waves hold (rs_cg_presolve); the direct path -- W factorised by the same panel scheme, its
+//       factor written packed to LDS, the two triangular sweeps by wave 0 -- is the fallback, and the only path for
+//       num_vars <= 64.
 //   P4  ADMM iterations.  Rows (variables) live in lanes, 64 per "row half" (RH = 1 or 2 halves), the columns of
 //       rho G are split over CSA = min(W / RH, 4 / RH) waves per half (one ADMM wave per SIMD; the others have left
 //       the kernel by then): every wave holds a 64 x (n / CSA) block of rho G in
 //       registers, forms its partial mat-vec with DPP-fed FMAs, the partial sums meet in LDS (barrier), and every
 //       wave of a half repeats the (cheap) projections for that half's rows, so only w crosses waves again
 //       (second barrier, not needed when RH == 1).
+//       num_vars > 64: the row-split layout (RowSplit below) -- four ADMM waves own 32 slots of variables each, the lane
+//       halves split the columns: one exchange and one barrier per iteration.
 //   P5  metrics and write-back.
+// Two-launch form (num_vars > 64, FCCQP_KERNEL_COOP_SPLIT): coop_kernel<.., 1> = P0 .. P3 at one QP per CU, hand-over of
+// the ADMM waves' rows of rho G through a device workspace (SplitWorkspace), coop_admm_kernel = Pw (conjugate gradients)
+// + P4 + P5 at three QPs per CU, coop_kernel<.., 2> = the whole solve again for the instances whose conjugate gradients
+// declined.  Bit-identical to the one-launch form.
 // Not bitwise equal to the one-wave kernel (the mat-vec sums its columns in another order); both are within 1e-12
 // of the oracle on the synthetic workloads.
 #pragma once
@@ -172,7 +181,7 @@ struct Shape {
   // (row split: w by position, [2][128] doubles by iteration parity)
   static constexpr int kRsW = 0;
   static constexpr int kPart = 0, kWvOff = 2 * CS * kPos, kAdmmLen = kRowSplit ? kRsW + 256 + 64 : kWvOff + ((RH == 1) ? W : 1) * kWv;
-  static constexpr int kBigLen = cmax(cmax(kVbufLen, kYbufLen), cmax(cmax(kImage, kWfacLen), kAdmmLen));
+  static constexpr int kBigLen = cmax(kVbufLen + kYbufLen, cmax(cmax(kImage, kWfacLen), kAdmmLen));   // (V and Y tiles side by side: the fused Gram product)
   static constexpr int kLdsDoubles = kBig + kBigLen;
   static_assert(kLdsDoubles * 8 <= 160 * 1024, "LDS of one CU");
 };
@@ -268,29 +277,27 @@ __device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &
 }
 
 // ---- P1: K_rho = U^T D U with the forward solve of [E | r] fused in, tile columns shared out over the waves ----
-// FUSE: the Gram product G = Y^T D^-1 Y is a sum over the row blocks of Y, and row block P of Y is final the moment
+// The Gram product G = Y^T D^-1 Y is a sum over the row blocks of Y, and row block P of Y is final the moment
 // panel P has solved it -- so its term is added right there: the owners publish Y_p beside V_p (same barrier), and every
 // wave adds (Y_p[.][I])^T D_p^-1 Y_p[.][J] to the accumulator tiles Gt[I][J] of its own columns J behind the trailing
 // update.  Against a Gram product of its own behind the factorisation (coop_gram: publish + barrier per row block)
 // eleven barriers and their LDS round trips go, the matrix-core work fills waits of the panels, and a row block of Y
 // is dead as soon as its panel ends.
-template <class SH, int WV, bool FUSE>
+template <class SH, int WV>
 __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, d4 (&C)[SH::NRB][SH::NRB],
                                                     d4 (&X)[SH::NRB][SH::NXB], d4 (&Gt)[SH::NW][SH::NXB]) {
   constexpr int N = SH::N, n = SH::n, NRB = SH::NRB, NXB = SH::NXB, cbd = SH::cbd;
   const int col = lane & 15, grp = lane >> 4;
   lds_f64 *const Sinv = L + SH::kSinv, *const Srcp = L + SH::kSrcp, *const rhs = L + SH::kRhs;
   lds_f64 *const Vbuf = L + SH::kBig;
-  lds_f64 *const Yfbuf = L + SH::kBig + SH::kVbufLen;          // FUSE: Y_p of two panels, behind the V tiles
-  static_assert(!FUSE || SH::kVbufLen + SH::kYbufLen <= SH::kBigLen, "room for the published Y tiles");
+  lds_f64 *const Yfbuf = L + SH::kBig + SH::kVbufLen;          // Y_p of two panels, behind the V tiles
+  static_assert(SH::kVbufLen + SH::kYbufLen <= SH::kBigLen, "room for the published Y tiles");
   constexpr int IMAX = SH::NW - 1;                             // last row block of G that is needed
-  if constexpr (FUSE) {
 #pragma unroll
-    for (int J = 0; J <= cbd; ++J)
-      if (SH::ownX(J) == WV)
+  for (int J = 0; J <= cbd; ++J)
+    if (SH::ownX(J) == WV)
 #pragma unroll
-        for (int I = 0; I <= ((J < IMAX) ? J : IMAX); ++I) Gt[I][J] = d4{0.0, 0.0, 0.0, 0.0};
-  }
+      for (int I = 0; I <= ((J < IMAX) ? J : IMAX); ++I) Gt[I][J] = d4{0.0, 0.0, 0.0, 0.0};
   lds_i32 *const iflags = (lds_i32 *)(L + SH::kInts);
   auto zero_tile = [](int K, int cb) { return K < cb && cb != cbd; };
   auto kfirst = [](int cb) { return (cb == cbd) ? 0 : cb; };
@@ -315,7 +322,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     if (lane < 16) L[SH::kRcp + 16 * Pn + col] = rmine;
     if (bad && lane == 0) iflags[0] = 1;
   };
-  // FUSE: the term of row block P of Y in the own accumulator tiles (nrv: -1/d of the panel's rows)
+  // the term of row block P of Y in the own accumulator tiles (nrv: -1/d of the panel's rows)
   auto gram_step = [&](auto pc, const double (&nrv)[4]) {
     constexpr int P = decltype(pc)::value;
 #pragma unroll
@@ -372,12 +379,10 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
         for (int r = 0; r < 4; ++r)
           if (16 * P + 4 * r < N) t = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[r], X[P][cb][r], t, 0, 0, 0);
         X[P][cb] = t;
-        if constexpr (FUSE) {
-          if (cb <= cbd) tile_publish(Yfbuf + ((P & 1) * NXB + cb) * SH::kTile, lane, t);
-        }
+        tile_publish(Yfbuf + ((P & 1) * NXB + cb) * SH::kTile, lane, t);
       }
     }
-    if constexpr (P + 1 == NRB && FUSE) {
+    if constexpr (P + 1 == NRB) {
       wg_barrier();
       gram_step(pc, nrv);
     }
@@ -426,63 +431,25 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
           }
         }
       }
-      if constexpr (FUSE) gram_step(pc, nrv);
+      gram_step(pc, nrv);
       wg_barrier();      // the next diagonal tile is published; every wave is done with the V tiles of panel P
     }
   });
 }
 
-// ---- P3: rho G and x_c as the Gram product Y^T D^-1 Y; own tile columns J (the owner of X column J) ---------------
-// Leaves rho G in the LDS image (row-major n x n), x_c in xcv[0..n), and the own upper tiles of W = I - rho G in Wt.
-// FUSED: the accumulator tiles Gt arrive complete from coop_factor_forward<.., true>; only the output half runs.
-template <class SH, int WV, bool FUSED>
-__device__ __forceinline__ void coop_gram(lds_f64 *L, const int lane, const double rho, const d4 (&X)[SH::NRB][SH::NXB],
-                                          d4 (&Gt)[SH::NW][SH::NXB], d4 (&Wt)[SH::NW][SH::NW]) {
-  constexpr int N = SH::N, n = SH::n, NRB = SH::NRB, NXB = SH::NXB, NW = SH::NW, cbd = SH::cbd;
+// ---- P3, output half: rho G and x_c out of the accumulator tiles of the Gram product Y^T D^-1 Y (own tile columns J:
+// the owner of X column J).  Leaves rho G in the LDS image (row-major n x n), x_c in xcv[0..n), and the own upper tiles
+// of W = I - rho G in Wt.
+// (The accumulation itself lives in the panels of coop_factor_forward since round 5; through round 4 it was a loop of
+// its own here -- publish row block K of Y, barrier, accumulate -- 17.4 us per QP for the large shape against 4.5 us
+// for this output half plus 8 us more in the factorisation.)
+template <class SH, int WV>
+__device__ __forceinline__ void coop_gram_output(lds_f64 *L, const int lane, const double rho, const d4 (&Gt)[SH::NW][SH::NXB],
+                                                 d4 (&Wt)[SH::NW][SH::NW]) {
+  constexpr int n = SH::n, NW = SH::NW, cbd = SH::cbd;
   const int col = lane & 15, grp = lane >> 4;
-  lds_f64 *const Ybuf = L + SH::kBig, *const img = L + SH::kBig, *const xcv = L + SH::kRhs;
-  auto kmin = [](int cb) { return (cb == cbd) ? 0 : cb; };
+  lds_f64 *const img = L + SH::kBig, *const xcv = L + SH::kRhs;
   constexpr int IMAX = NW - 1;                      // last row block of G that is needed
-  if constexpr (!FUSED) {
-#pragma unroll
-  for (int J = 0; J <= cbd; ++J)
-    if (SH::ownX(J) == WV)
-#pragma unroll
-      for (int I = 0; I <= ((J < IMAX) ? J : IMAX); ++I) Gt[I][J] = d4{0.0, 0.0, 0.0, 0.0};
-  wg_barrier();      // the last panel's readers of the published V tiles are done: the buffer is reused
-  static_for<0, NRB>([&](auto kc) {
-    constexpr int K = decltype(kc)::value;
-    // publish the own non-zero tiles of row block K of Y
-#pragma unroll
-    for (int cb = 0; cb <= cbd; ++cb)
-      if (SH::ownX(cb) == WV && K >= kmin(cb)) tile_publish(Ybuf + ((K & 1) * NXB + cb) * SH::kTile, lane, X[K][cb]);
-    wg_barrier();
-    double rd[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rd[r] = L[SH::kRcp + 16 * K + grp + 4 * r];
-#pragma unroll
-    for (int I = 0; I <= IMAX; ++I) {
-      if (K >= kmin(I)) {
-        bool any = false;
-#pragma unroll
-        for (int J = I; J <= cbd; ++J) any = any || (SH::ownX(J) == WV && K >= kmin(J));
-        if (any) {
-          const d4 y = tile_fetch(Ybuf + ((K & 1) * NXB + I) * SH::kTile, lane);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (4 * (4 * K + r) < N) {
-              const double aop = y[r] * rd[r];
-#pragma unroll
-              for (int J = I; J <= cbd; ++J)
-                if (SH::ownX(J) == WV && K >= kmin(J))
-                  Gt[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[K][J][r], Gt[I][J], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-  });
-  }   // (!FUSED)
   wg_barrier();      // every wave is done with the published Y tiles: the image goes over them
 #pragma unroll
   for (int J = 0; J <= cbd; ++J) {
@@ -1117,11 +1084,6 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
   // own 32 slots of variables each (lane & 31; both lane halves hold the slot's variable), the lane half picks the
   // column half of rho G.
   constexpr bool kRS = SH::kRowSplit;
-#ifdef FCCQP_COOP_FUSE_GRAM_ALWAYS
-  constexpr bool kFuseGram = true;
-#else
-  constexpr bool kFuseGram = SPLIT;                 // (Gram product inside the factorisation's panels: first launch of the two-launch form)
-#endif
   using RS = typename SH::RS;
   constexpr int h = kRS ? 0 : WV % RH, c = kRS ? 0 : WV / RH;
   const int half = lane >> 5, slot = lane & 31;
@@ -1168,10 +1130,10 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       ph_asm = t0 - t_begin;
       wg_barrier();                                   // rhs and the cleared flags are visible
       d4 Gt[NW][SH::NXB];
-      coop_factor_forward<SH, WV, kFuseGram>(L, lane, C, X, Gt);
+      coop_factor_forward<SH, WV>(L, lane, C, X, Gt);
       const long long t3 = wall_clock64();
       ticks = t3 - t0;
-      coop_gram<SH, WV, kFuseGram>(L, lane, a.rho, X, Gt, Wt);
+      coop_gram_output<SH, WV>(L, lane, a.rho, Gt, Wt);
       t4 = wall_clock64();
       ph_p3 = t4 - t3;
     }

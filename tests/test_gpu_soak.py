@@ -75,8 +75,10 @@ def test_cooperative_kernel_repetitions_on_three_concurrent_handles(nb, reps):
     import fcc_qp_amd as F
     from fcc_qp_amd import problems as P
 
-    kernels = ("coop", "coop", "generic")
-    kmap = {"coop": F.KERNEL_COOP, "generic": F.KERNEL_GENERIC}
+    # (batch 1024: the second handle runs the two-launch form -- three launches and a device workspace per solve --, whose
+    # results are the one-launch kernel's bit for bit)
+    kernels = ("coop", "coop_split" if nb >= 1024 else "coop", "generic")
+    kmap = {"coop": F.KERNEL_COOP, "coop_split": F.KERNEL_COOP_SPLIT, "generic": F.KERNEL_GENERIC}
     dev = torch.device("cuda", 0)
     base = P.workload("W-mix", nb, P.LARGE, distinct=16)
     handles = []
@@ -107,7 +109,7 @@ def test_cooperative_kernel_repetitions_on_three_concurrent_handles(nb, reps):
                     bad[h] += (a != b).sum()
     torch.cuda.synchronize()
     assert [int(b.item()) for b in bad] == [0, 0, 0], f"repetitions differed: {[int(b.item()) for b in bad]} words"
-    assert [s.kernel_in_use() for s, _, _ in handles] == [F.KERNEL_COOP, F.KERNEL_COOP, F.KERNEL_GENERIC]
+    assert [s.kernel_in_use() for s, _, _ in handles] == [kmap[k] for k in kernels]
     z0 = first[0]["z"].cpu().numpy()
     z1 = np.roll(first[1]["z"].cpu().numpy(), -3, axis=0)
     z2 = np.roll(first[2]["z"].cpu().numpy(), -6, axis=0)
@@ -139,6 +141,6 @@ def test_cooperative_kernel_host_pointer_solves_on_fresh_handles(nb):
             it = [x.n_iter for x in d]
             if ref is None:
                 ref = (z.copy(), it)
-                assert s.kernel() == CAPI.KERNEL_COOP
+                assert s.kernel() == (CAPI.KERNEL_COOP if nb == 16 else CAPI.KERNEL_COOP_SPLIT)     # (what AUTO takes)
             assert np.array_equal(z, ref[0]) and it == ref[1], f"solve {done} differs from the first"
         s.close()

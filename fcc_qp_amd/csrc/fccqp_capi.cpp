@@ -54,6 +54,12 @@ struct fccqp_solver {
   // fallback-list launch is issued only if an instance was flagged (pending_fb)
   char *hin_dev = nullptr;
   bool hres_fresh = false;
+  // Transfers between CALLER memory and the device go through two page-locked bounce buffers of the handle (copy_in /
+  // copy_out below): the GPU never addresses the caller's pages.  See the note at copy_in.
+  char *bounce[2] = {nullptr, nullptr};
+  hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+  bool bounce_busy[2] = {false, false};
+  int bounce_next = 0;
   // the last solve was waited for on the host and recorded no events (a timing event costs ~5 us of stream time
   // each; a one-QP solve is 50-90 us): nothing is left to wait for, and fccqp_last_kernel_ms reports host_device_ms,
   // the host-measured time from the launch to the completion of the device work
@@ -175,6 +181,135 @@ constexpr double kSelfCheckTol = 1e-6;
 // (the one-launch kernel runs one QP per CU at a time: below two rounds the second launch's ramp is not repaid)
 constexpr int kCoopSplitMinBatchPerCu = 2;
 size_t align256(size_t v) { return (v + 255u) & ~size_t(255); }
+
+// ---- transfers between CALLER memory and the device ---------------------------------------------------------------
+// For a copy of 1 MiB or more out of (or into) pageable memory the HIP runtime page-locks the CALLER's pages on the fly
+// and lets a copy kernel read them in place ("HSA Copy Using Pinned resource" in its own log, tools/pageable_copy_probe.py;
+// smaller copies go through the runtime's staging buffers), and it keeps such locks cached by address.  Both process
+// aborts this library has seen -- one of eleven runs of the GPU test suite in round 4, one of six in round 5: "Memory access
+// fault by GPU node-2 on address 0x64bef7d16000", an address in the middle of the process's malloc heap -- were host-pointer
+// solves whose Q array is >= 1 MiB, out of numpy arrays that had been allocated and freed many times over in that process:
+// the only way a GPU ever sees a heap address here is that path.  What exactly goes stale inside the runtime (the cached
+// lock of pages the allocator has since returned to the kernel is the candidate) was not reproduced in isolation
+// (tools/pageable_churn_stress.py: 3000 solves clean), so the remedy does not depend on it: memory that is not page-locked
+// already is copied by the CPU into / out of two page-locked bounce buffers of the handle, and only those are handed to the
+// DMA engines.  The copy out of the caller's arrays is complete when a solve entry point returns, whatever the stream is
+// still doing.  Page-locked caller memory (hipHostMalloc / hipHostRegister: the fccqp_solve_async contract) is used in place.
+constexpr size_t kBounceBytes = size_t(4) << 20;
+
+bool page_locked(const void *p) {
+  hipPointerAttribute_t a;
+  const hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+int ensure_bounce(fccqp_solver *s) {
+  if (s->bounce[1]) return FCCQP_OK;
+  for (int k = 0; k < 2; ++k) {
+    if (!s->bounce[k]) HIP_TRY(s, hipHostMalloc(reinterpret_cast<void **>(&s->bounce[k]), kBounceBytes, hipHostMallocDefault));
+    if (!s->bounce_ev[k]) HIP_TRY(s, hipEventCreateWithFlags(&s->bounce_ev[k], hipEventDisableTiming));
+  }
+  return FCCQP_OK;
+}
+
+// the next bounce buffer, free of the DMA that last used it
+int take_bounce(fccqp_solver *s, int *k_out) {
+  const int rc = ensure_bounce(s);
+  if (rc != FCCQP_OK) return rc;
+  const int k = s->bounce_next;
+  s->bounce_next ^= 1;
+  if (s->bounce_busy[k]) {
+    HIP_TRY(s, hipEventSynchronize(s->bounce_ev[k]));
+    s->bounce_busy[k] = false;
+  }
+  *k_out = k;
+  return FCCQP_OK;
+}
+
+// host -> device on `st`, `rows` rows of `row_bytes` (source rows `src_pitch` apart, destination rows dense).  Returns when
+// the caller's memory has been read; the DMA out of the bounce buffers may still be running.
+int copy_in_rows(fccqp_solver *s, void *dst, const void *src, size_t row_bytes, size_t src_pitch, size_t rows, hipStream_t st) {
+  if (!row_bytes || !rows) return FCCQP_OK;
+  const char *from = static_cast<const char *>(src);
+  char *to = static_cast<char *>(dst);
+  if (page_locked(src)) {
+    if (src_pitch == row_bytes) HIP_TRY(s, hipMemcpyAsync(to, from, row_bytes * rows, hipMemcpyHostToDevice, st));
+    else HIP_TRY(s, hipMemcpy2DAsync(to, row_bytes, from, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, st));
+    return FCCQP_OK;
+  }
+  if (src_pitch == row_bytes) {              // one dense run: cut into bounce-sized pieces
+    const size_t bytes = row_bytes * rows;
+    for (size_t off = 0; off < bytes; off += kBounceBytes) {
+      const size_t len = (bytes - off < kBounceBytes) ? bytes - off : kBounceBytes;
+      int k = 0;
+      const int rc = take_bounce(s, &k);
+      if (rc != FCCQP_OK) return rc;
+      std::memcpy(s->bounce[k], from + off, len);
+      HIP_TRY(s, hipMemcpyAsync(to + off, s->bounce[k], len, hipMemcpyHostToDevice, st));
+      HIP_TRY(s, hipEventRecord(s->bounce_ev[k], st));
+      s->bounce_busy[k] = true;
+    }
+    return FCCQP_OK;
+  }
+  if (row_bytes > kBounceBytes) return fail(s, FCCQP_ERR_INVALID_ARG, "row longer than a bounce buffer");
+  const size_t per = kBounceBytes / row_bytes;
+  for (size_t r0 = 0; r0 < rows; r0 += per) {
+    const size_t nr = (rows - r0 < per) ? rows - r0 : per;
+    int k = 0;
+    const int rc = take_bounce(s, &k);
+    if (rc != FCCQP_OK) return rc;
+    for (size_t r = 0; r < nr; ++r) std::memcpy(s->bounce[k] + r * row_bytes, from + (r0 + r) * src_pitch, row_bytes);
+    HIP_TRY(s, hipMemcpyAsync(to + r0 * row_bytes, s->bounce[k], nr * row_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(s, hipEventRecord(s->bounce_ev[k], st));
+    s->bounce_busy[k] = true;
+  }
+  return FCCQP_OK;
+}
+int copy_in(fccqp_solver *s, void *dst, const void *src, size_t bytes, hipStream_t st) {
+  return copy_in_rows(s, dst, src, bytes, bytes, 1, st);
+}
+
+// device -> host on `st`; returns when the caller's memory holds the data.  (The caller of this function has waited for
+// whatever produces `src`, or enqueued this behind it on `st`.)
+int copy_out(fccqp_solver *s, void *dst, const void *src, size_t bytes, hipStream_t st) {
+  if (!bytes) return FCCQP_OK;
+  char *to = static_cast<char *>(dst);
+  const char *from = static_cast<const char *>(src);
+  if (page_locked(dst)) {
+    HIP_TRY(s, hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    return FCCQP_OK;
+  }
+  // piece i + 1 is on its way into the other bounce buffer while the CPU copies piece i out of this one
+  size_t issued = 0, drained = 0;
+  int slot[2] = {0, 0};
+  size_t len_of[2] = {0, 0};
+  int head = 0, tail = 0, inflight = 0;
+  while (drained < bytes) {
+    while (inflight < 2 && issued < bytes) {
+      const size_t len = (bytes - issued < kBounceBytes) ? bytes - issued : kBounceBytes;
+      int k = 0;
+      const int rc = take_bounce(s, &k);
+      if (rc != FCCQP_OK) return rc;
+      HIP_TRY(s, hipMemcpyAsync(s->bounce[k], from + issued, len, hipMemcpyDeviceToHost, st));
+      HIP_TRY(s, hipEventRecord(s->bounce_ev[k], st));
+      s->bounce_busy[k] = true;
+      slot[head] = k; len_of[head] = len; head ^= 1;
+      issued += len; ++inflight;
+    }
+    const int k = slot[tail];
+    HIP_TRY(s, hipEventSynchronize(s->bounce_ev[k]));
+    s->bounce_busy[k] = false;
+    std::memcpy(to + drained, s->bounce[k], len_of[tail]);
+    drained += len_of[tail];
+    tail ^= 1; --inflight;
+  }
+  return FCCQP_OK;
+}
 
 int ensure_staging(fccqp_solver *s) {
   if (s->din_block) return FCCQP_OK;
@@ -419,6 +554,7 @@ void reset_after_failed_solve(fccqp_solver *s, hipStream_t stream) {
   if (s->dfb_count) (void)hipMemsetAsync(s->dfb_count, 0, 2 * sizeof(int), stream);
   (void)hipStreamSynchronize(stream);
   (void)hipGetLastError();
+  s->bounce_busy[0] = s->bounce_busy[1] = false;
   s->fb_deferred = false;
   s->hres_fresh = false;
   s->solved = false;
@@ -639,7 +775,12 @@ int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_
 int fccqp_destroy(fccqp_solver *s) {
   if (!s) return FCCQP_OK;
   DeviceGuard g(s->device);
+  // nothing of the handle may still be in use: the last solve (wherever it was enqueued -- its kernels write the
+  // page-locked words and blocks freed below), a result copy on the solver's stream, DMA out of the bounce buffers
+  if (s->ev1) (void)wait_last(s);
+  if (s->copy_pending && s->ev2) (void)hipEventSynchronize(s->ev2);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
+  (void)hipGetLastError();
   void *ptrs[] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub, s->din_block, s->dres_block, s->dmux, s->dmulc,
                   s->dwork, s->dphase, s->dfb_list, s->dfb_count, s->dcod_ws, s->dticket, s->dsplit};
   for (void *p : ptrs)
@@ -647,6 +788,10 @@ int fccqp_destroy(fccqp_solver *s) {
   if (s->fb_seen) (void)hipHostFree(const_cast<int *>(s->fb_seen));
   if (s->hin_block) (void)hipHostFree(s->hin_block);
   if (s->hres_block) (void)hipHostFree(s->hres_block);
+  for (int k = 0; k < 2; ++k) {
+    if (s->bounce[k]) (void)hipHostFree(s->bounce[k]);
+    if (s->bounce_ev[k]) (void)hipEventDestroy(s->bounce_ev[k]);
+  }
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev2) (void)hipEventDestroy(s->ev2);
@@ -804,6 +949,13 @@ int fccqp_get_z_async(fccqp_solver *s, double *z_pinned) {
   DeviceGuard g(s->device);
   // behind the last solve, wherever it was enqueued
   if (!s->quiesced && s->last_stream != s->stream) HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev1, 0));
+  if (!page_locked(z_pinned)) {
+    // not what the contract asks for: the copy is done here, through the bounce buffers, and is complete on return
+    const int rc = copy_out(s, z_pinned, s->dx, sizeof(double) * (size_t)s->batch * (size_t)s->n, s->stream);
+    if (rc != FCCQP_OK) return rc;
+    s->copy_pending = false;
+    return FCCQP_OK;
+  }
   HIP_TRY(s, hipMemcpyAsync(z_pinned, s->dx, sizeof(double) * (size_t)s->batch * (size_t)s->n,
                             hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipEventRecord(s->ev2, s->stream));
@@ -889,21 +1041,17 @@ int solve_host(fccqp_solver *s, const double *Q, const double *b, const double *
     return FCCQP_OK;
   }
   rc = [&]() -> int {
-    HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(double) * B * n * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(s, hipMemcpyAsync(s->db, b, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-    if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(double) * B * m * n, hipMemcpyHostToDevice, st));
-    if (m) HIP_TRY(s, hipMemcpyAsync(s->dbeq, b_eq, sizeof(double) * B * m, hipMemcpyHostToDevice, st));
-    if (nm) {
-      if ((size_t)n_friction == nm) {
-        HIP_TRY(s, hipMemcpyAsync(s->dmu, friction_coeffs, sizeof(double) * B * nm, hipMemcpyHostToDevice, st));
-      } else {  // keep the first nc/3 of every instance's row
-        HIP_TRY(s, hipMemcpy2DAsync(s->dmu, sizeof(double) * nm, friction_coeffs,
-                                    sizeof(double) * (size_t)n_friction, sizeof(double) * nm, B,
-                                    hipMemcpyHostToDevice, st));
-      }
-    }
-    HIP_TRY(s, hipMemcpyAsync(s->dlb, lb, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(s, hipMemcpyAsync(s->dub, ub, sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+    // (copy_in: page-locked arrays in place, anything else through the handle's bounce buffers -- the GPU never
+    // addresses pageable caller memory)
+    int rc2 = copy_in(s, s->dQ, Q, sizeof(double) * B * n * n, st);
+    if (rc2 == FCCQP_OK) rc2 = copy_in(s, s->db, b, sizeof(double) * B * n, st);
+    if (rc2 == FCCQP_OK && m * n) rc2 = copy_in(s, s->dA, A_eq, sizeof(double) * B * m * n, st);
+    if (rc2 == FCCQP_OK && m) rc2 = copy_in(s, s->dbeq, b_eq, sizeof(double) * B * m, st);
+    if (rc2 == FCCQP_OK && nm)   // keep the first nc/3 of every instance's row
+      rc2 = copy_in_rows(s, s->dmu, friction_coeffs, sizeof(double) * nm, sizeof(double) * (size_t)n_friction, B, st);
+    if (rc2 == FCCQP_OK) rc2 = copy_in(s, s->dlb, lb, sizeof(double) * B * n, st);
+    if (rc2 == FCCQP_OK) rc2 = copy_in(s, s->dub, ub, sizeof(double) * B * n, st);
+    if (rc2 != FCCQP_OK) return rc2;
     return enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st);
   }();
   if (rc != FCCQP_OK) {
@@ -964,10 +1112,11 @@ int fccqp_solve_async_f32(fccqp_solver *s, const float *Q, const float *b, const
   const size_t cnt[5] = {B * n, B * m, B * nm, B * n, B * n};
   if (B * (3 * n + m + nm) > B * n * n) return fail(s, FCCQP_ERR_UNSUPPORTED, "shape too small for the float staging layout");
   rc = [&]() -> int {
-    HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));
-    if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(float) * B * m * n, hipMemcpyHostToDevice, st));
-    for (int i = 0; i < 5; ++i)
-      if (cnt[i]) HIP_TRY(s, hipMemcpyAsync(dv[i], hv[i], sizeof(float) * cnt[i], hipMemcpyHostToDevice, st));
+    int rc2 = copy_in(s, s->dQ, Q, sizeof(float) * B * n * n, st);
+    if (rc2 == FCCQP_OK && m * n) rc2 = copy_in(s, s->dA, A_eq, sizeof(float) * B * m * n, st);
+    for (int i = 0; i < 5 && rc2 == FCCQP_OK; ++i)
+      if (cnt[i]) rc2 = copy_in(s, dv[i], hv[i], sizeof(float) * cnt[i], st);
+    if (rc2 != FCCQP_OK) return rc2;
     const float *const src[5] = {dv[0], dv[1], dv[2], dv[3], dv[4]};
     double *const dst[5] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub};
     HIP_TRY(s, fccqp::launch_widen5(src, dst, cnt, st));
@@ -1024,13 +1173,14 @@ int fccqp_solve_f32(fccqp_solver *s, const float *Q, const float *b, const float
   for (size_t i = 0; i < B; ++i)
     for (size_t c = 0; c < nm; ++c) wmu[i * nm + c] = (double)friction_coeffs[i * (size_t)n_friction + c];
   rc = [&]() -> int {
-    HIP_TRY(s, hipMemcpyAsync(s->dQ, Q, sizeof(float) * B * n * n, hipMemcpyHostToDevice, st));
-    if (m * n) HIP_TRY(s, hipMemcpyAsync(s->dA, A_eq, sizeof(float) * B * m * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(s, hipMemcpyAsync(s->db, wb.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-    if (m) HIP_TRY(s, hipMemcpyAsync(s->dbeq, wbeq.data(), sizeof(double) * B * m, hipMemcpyHostToDevice, st));
-    if (nm) HIP_TRY(s, hipMemcpyAsync(s->dmu, wmu.data(), sizeof(double) * B * nm, hipMemcpyHostToDevice, st));
-    HIP_TRY(s, hipMemcpyAsync(s->dlb, wlb.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(s, hipMemcpyAsync(s->dub, wub.data(), sizeof(double) * B * n, hipMemcpyHostToDevice, st));
+    int rc2 = copy_in(s, s->dQ, Q, sizeof(float) * B * n * n, st);
+    if (rc2 == FCCQP_OK && m * n) rc2 = copy_in(s, s->dA, A_eq, sizeof(float) * B * m * n, st);
+    if (rc2 == FCCQP_OK) rc2 = copy_in(s, s->db, wb.data(), sizeof(double) * B * n, st);
+    if (rc2 == FCCQP_OK && m) rc2 = copy_in(s, s->dbeq, wbeq.data(), sizeof(double) * B * m, st);
+    if (rc2 == FCCQP_OK && nm) rc2 = copy_in(s, s->dmu, wmu.data(), sizeof(double) * B * nm, st);
+    if (rc2 == FCCQP_OK) rc2 = copy_in(s, s->dlb, wlb.data(), sizeof(double) * B * n, st);
+    if (rc2 == FCCQP_OK) rc2 = copy_in(s, s->dub, wub.data(), sizeof(double) * B * n, st);
+    if (rc2 != FCCQP_OK) return rc2;
     return enqueue(s, s->dQ, s->db, s->dA, s->dbeq, s->dmu, s->dlb, s->dub, st, /*qa_f32=*/true);
   }();
   if (rc != FCCQP_OK) {
@@ -1065,7 +1215,8 @@ int fccqp_get_solution(fccqp_solver *s, double *z, fccqp_details *details) {
     if (!s->hres_fresh) HIP_TRY(s, hipMemcpy(s->hres_block, s->dres_block, s->res_bytes, hipMemcpyDeviceToHost));
     if (z && n) std::memcpy(z, s->hres_block + s->res_off[0], sizeof(double) * B * n);
   } else if (z && n) {
-    HIP_TRY(s, hipMemcpy(z, s->dx, sizeof(double) * B * n, hipMemcpyDeviceToHost));
+    const int rc = copy_out(s, z, s->dx, sizeof(double) * B * n, s->stream);
+    if (rc != FCCQP_OK) return rc;
   }
   if (details) {
     std::vector<int> it(B), fl(B);
@@ -1077,10 +1228,11 @@ int fccqp_get_solution(fccqp_solver *s, double *z, fccqp_details *details) {
       std::memcpy(it.data(), s->hres_block + s->res_off[3], sizeof(int) * B);
       std::memcpy(fl.data(), s->hres_block + s->res_off[4], sizeof(int) * B);
     } else {
-      HIP_TRY(s, hipMemcpy(it.data(), s->dniter, sizeof(int) * B, hipMemcpyDeviceToHost));
-      HIP_TRY(s, hipMemcpy(fl.data(), s->dflags, sizeof(int) * B, hipMemcpyDeviceToHost));
-      HIP_TRY(s, hipMemcpy(met.data(), s->dmetrics, sizeof(double) * 4 * B, hipMemcpyDeviceToHost));
-      HIP_TRY(s, hipMemcpy(tk.data(), s->dticks, sizeof(long long) * B, hipMemcpyDeviceToHost));
+      int rc = copy_out(s, it.data(), s->dniter, sizeof(int) * B, s->stream);
+      if (rc == FCCQP_OK) rc = copy_out(s, fl.data(), s->dflags, sizeof(int) * B, s->stream);
+      if (rc == FCCQP_OK) rc = copy_out(s, met.data(), s->dmetrics, sizeof(double) * 4 * B, s->stream);
+      if (rc == FCCQP_OK) rc = copy_out(s, tk.data(), s->dticks, sizeof(long long) * B, s->stream);
+      if (rc != FCCQP_OK) return rc;
     }
     double wall = s->last_solve_wall;
     if (wall == 0.0) {  // device-pointer solve: report the kernel time instead
@@ -1122,11 +1274,11 @@ int fccqp_get_state(fccqp_solver *s, double *x, double *mu_x, double *mu_lambda_
   DeviceGuard g(s->device);
   HIP_TRY(s, wait_last(s));
   const size_t B = (size_t)s->batch, n = (size_t)s->n, nc = (size_t)s->nc;
-  if (x && n) HIP_TRY(s, hipMemcpy(x, s->dx, sizeof(double) * B * n, hipMemcpyDeviceToHost));
-  if (mu_x && n) HIP_TRY(s, hipMemcpy(mu_x, s->dmux, sizeof(double) * B * n, hipMemcpyDeviceToHost));
-  if (mu_lambda_c && nc)
-    HIP_TRY(s, hipMemcpy(mu_lambda_c, s->dmulc, sizeof(double) * B * nc, hipMemcpyDeviceToHost));
-  return FCCQP_OK;
+  int rc = FCCQP_OK;
+  if (x && n) rc = copy_out(s, x, s->dx, sizeof(double) * B * n, s->stream);
+  if (rc == FCCQP_OK && mu_x && n) rc = copy_out(s, mu_x, s->dmux, sizeof(double) * B * n, s->stream);
+  if (rc == FCCQP_OK && mu_lambda_c && nc) rc = copy_out(s, mu_lambda_c, s->dmulc, sizeof(double) * B * nc, s->stream);
+  return rc;
 }
 
 int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x, const double *mu_lambda_c) {
@@ -1135,10 +1287,14 @@ int fccqp_set_state(fccqp_solver *s, const double *x, const double *mu_x, const 
   HIP_TRY(s, wait_last(s));
   s->hres_fresh = false;               // x doubles as z: the page-locked copy of the results is stale now
   const size_t B = (size_t)s->batch, n = (size_t)s->n, nc = (size_t)s->nc;
-  if (x && n) HIP_TRY(s, hipMemcpy(s->dx, x, sizeof(double) * B * n, hipMemcpyHostToDevice));
-  if (mu_x && n) HIP_TRY(s, hipMemcpy(s->dmux, mu_x, sizeof(double) * B * n, hipMemcpyHostToDevice));
-  if (mu_lambda_c && nc)
-    HIP_TRY(s, hipMemcpy(s->dmulc, mu_lambda_c, sizeof(double) * B * nc, hipMemcpyHostToDevice));
+  int rc = FCCQP_OK;
+  if (x && n) rc = copy_in(s, s->dx, x, sizeof(double) * B * n, s->stream);
+  if (rc == FCCQP_OK && mu_x && n) rc = copy_in(s, s->dmux, mu_x, sizeof(double) * B * n, s->stream);
+  if (rc == FCCQP_OK && mu_lambda_c && nc) rc = copy_in(s, s->dmulc, mu_lambda_c, sizeof(double) * B * nc, s->stream);
+  if (rc != FCCQP_OK) return rc;
+  // (the state is in place before the call returns, as with the blocking copies this replaces; a following solve on
+  // another stream is ordered behind it by that)
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
   return FCCQP_OK;
 }
 
@@ -1188,7 +1344,7 @@ int fccqp_phase_seconds(fccqp_solver *s, double out[8]) {
   if (!s->solved) return FCCQP_OK;
   HIP_TRY(s, wait_last(s));
   std::vector<long long> h(8 * B);
-  HIP_TRY(s, hipMemcpy(h.data(), s->dphase, sizeof(long long) * 8 * B, hipMemcpyDeviceToHost));
+  { const int rc = copy_out(s, h.data(), s->dphase, sizeof(long long) * 8 * B, s->stream); if (rc != FCCQP_OK) return rc; }
   for (int p = 0; p < 8; ++p) {
     double acc = 0.0;
     for (size_t i = 0; i < B; ++i) acc += (double)h[(size_t)p * B + i];
@@ -1203,7 +1359,7 @@ int fccqp_debug_phase_ticks(fccqp_solver *s, long long *out, long long count) {
   const long long have = s->dphase ? 8ll * s->batch : 0;
   if (!s->solved || count > have) return FCCQP_ERR_INVALID_ARG;
   HIP_TRY(s, wait_last(s));
-  HIP_TRY(s, hipMemcpy(out, s->dphase, sizeof(long long) * (size_t)count, hipMemcpyDeviceToHost));
+  { const int rc = copy_out(s, out, s->dphase, sizeof(long long) * (size_t)count, s->stream); if (rc != FCCQP_OK) return rc; }
   return FCCQP_OK;
 }
 
@@ -1219,7 +1375,7 @@ int fccqp_debug_read_workspace(fccqp_solver *s, double *out, long long count, lo
   const long long have = s->dwork ? (long long)s->batch * s->work_stride : 0;
   if (available) *available = have;
   const long long take = count < have ? count : have;
-  if (out && take > 0) HIP_TRY(s, hipMemcpy(out, s->dwork, sizeof(double) * (size_t)take, hipMemcpyDeviceToHost));
+  if (out && take > 0) { const int rc = copy_out(s, out, s->dwork, sizeof(double) * (size_t)take, s->stream); if (rc != FCCQP_OK) return rc; }
   return FCCQP_OK;
 }
 

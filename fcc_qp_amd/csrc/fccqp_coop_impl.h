@@ -276,6 +276,34 @@ __device__ __forceinline__ bool diag_tile(lds_f64 *L, const int lane, const d4 &
   return bad;
 }
 
+// which steps of a panel's trailing work (coop_factor_forward: `trailing`) wave WV takes part in -- step t < nV: row block
+// P + 1 + t of the trailing update, step nV + I: row block I of the panel's Gram term
+template <class SH, int WV, int P, bool kOwnNext>
+struct TrailingSteps {
+  static constexpr int NRB = SH::NRB, NXB = SH::NXB, cbd = SH::cbd;
+  static constexpr int nV = NRB - 1 - P, nY = SH::NW, nT = nV + nY;
+  static constexpr bool zero_tile(int K, int cb) { return K < cb && cb != cbd; }
+  static constexpr bool needed(const int t) {
+    if (t < nV) {
+      const int I = P + 1 + t;
+      bool any = false;
+      for (int J = I; J < NRB; ++J) any = any || (SH::ownC(J) == WV && !(kOwnNext && I == P + 1 && J == P + 1));
+      for (int cb = 0; cb < NXB; ++cb) any = any || (SH::ownX(cb) == WV && !zero_tile(P, cb));
+      return any;
+    }
+    const int I = t - nV;
+    if (zero_tile(P, I)) return false;
+    bool any = false;
+    for (int J = I; J <= cbd; ++J) any = any || (SH::ownX(J) == WV && !zero_tile(P, J));
+    return any;
+  }
+  static constexpr int next_needed(const int t) {
+    int u = t;
+    while (u < nT && !needed(u)) ++u;
+    return u;
+  }
+};
+
 // ---- P1: K_rho = U^T D U with the forward solve of [E | r] fused in, tile columns shared out over the waves ----
 // The Gram product G = Y^T D^-1 Y is a sum over the row blocks of Y, and row block P of Y is final the moment
 // panel P has solved it -- so its term is added right there: the owners publish Y_p beside V_p (same barrier), and every
@@ -322,21 +350,64 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     if (lane < 16) L[SH::kRcp + 16 * Pn + col] = rmine;
     if (bad && lane == 0) iflags[0] = 1;
   };
-  // the term of row block P of Y in the own accumulator tiles (nrv: -1/d of the panel's rows)
-  auto gram_step = [&](auto pc, const double (&nrv)[4]) {
+  // ---- the trailing work of panel P as ONE stream of A operands out of LDS: the published tiles V_p[.][I] of the rows
+  // I > P (trailing update of the own columns of C and X), then the published tiles Y_p[.][I] (the panel's term of the
+  // Gram product in the own accumulator tiles).  Step t's tile is fetched while step t - 1 computes: left to the
+  // compiler every row waited for its own LDS round trip (ds_read, s_waitcnt, then the MFMAs), which two waves per SIMD
+  // only partly hide.  `skip_first`: the owner of column P + 1 has updated and factorised its diagonal tile already.
+  auto trailing = [&](auto pc, auto skipc, const double (&nrv)[4]) {
     constexpr int P = decltype(pc)::value;
+    constexpr bool kOwnNext = decltype(skipc)::value != 0;
+    constexpr int nV = NRB - 1 - P, nY = IMAX + 1, nT = nV + nY;
+    using TS = TrailingSteps<SH, WV, P, kOwnNext>;
+    auto needed = [](const int t) constexpr { return TS::needed(t); };
+    auto next_needed = [](const int t) constexpr { return TS::next_needed(t); };
+    auto a_tile = [&](const int t) {
+      return (t < nV) ? Vbuf + ((P & 1) * NRB + (P + 1 + t)) * SH::kTile : Yfbuf + ((P & 1) * NXB + (t - nV)) * SH::kTile;
+    };
+    constexpr int t0 = next_needed(0);
+    d4 nxt = d4{0.0, 0.0, 0.0, 0.0};
+    if constexpr (t0 < nT) nxt = tile_fetch(a_tile(t0), lane);
+    static_for<0, nT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if constexpr (t < nV) {
+        // (right-hand-side tiles that come into being with this panel)
+        constexpr int I = P + 1 + t;
 #pragma unroll
-    for (int I = 0; I <= IMAX; ++I) {
-      if (!zero_tile(P, I)) {
-        bool any = false;
-#pragma unroll
-        for (int J = I; J <= cbd; ++J) any = any || (SH::ownX(J) == WV && !zero_tile(P, J));
-        if (any) {
-          const d4 y = tile_fetch(Yfbuf + ((P & 1) * NXB + I) * SH::kTile, lane);
+        for (int cb = 0; cb < NXB; ++cb)
+          if (SH::ownX(cb) == WV && !zero_tile(P, cb) && P == kfirst(cb)) X[I][cb] = x_initial(I, cb);
+      }
+      if constexpr (needed(t)) {
+        const d4 a = nxt;
+        constexpr int tn = next_needed(t + 1);
+        if constexpr (tn < nT) {
+          nxt = tile_fetch(a_tile(tn), lane);
+#ifndef FCCQP_COOP_NO_PREFETCH
+          __builtin_amdgcn_sched_barrier(0);           // (the fetch stays in front of this step's MFMAs)
+#endif
+        }
+        if constexpr (t < nV) {
+          constexpr int I = P + 1 + t;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (16 * P + 4 * r < N) {
-              const double aop = y[r] * -nrv[r];
+              const double aop = a[r] * nrv[r];        // A[i][k] = -(V_pi[4r + k][i] / d_{4r + k})
+#pragma unroll
+              for (int J = I; J < NRB; ++J)
+                if (SH::ownC(J) == WV && !(kOwnNext && I == P + 1 && J == P + 1))
+                  C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
+#pragma unroll
+              for (int cb = 0; cb < NXB; ++cb)
+                if (SH::ownX(cb) == WV && !zero_tile(P, cb))
+                  X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[P][cb][r], X[I][cb], 0, 0, 0);
+            }
+          }
+        } else {
+          constexpr int I = t - nV;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (16 * P + 4 * r < N) {
+              const double aop = a[r] * -nrv[r];
 #pragma unroll
               for (int J = I; J <= cbd; ++J)
                 if (SH::ownX(J) == WV && !zero_tile(P, J))
@@ -345,7 +416,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
           }
         }
       }
-    }
+    });
   };
   if constexpr (SH::ownC(0) == WV) factor_diag(int_c<0>{});
   wg_barrier();
@@ -384,7 +455,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
     }
     if constexpr (P + 1 == NRB) {
       wg_barrier();
-      gram_step(pc, nrv);
+      trailing(pc, int_c<0>{}, nrv);
     }
     if constexpr (P + 1 < NRB) {
       wg_barrier();
@@ -402,36 +473,7 @@ __device__ __forceinline__ void coop_factor_forward(lds_f64 *L, const int lane, 
             C[P + 1][P + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[r] * nrv[r], C[P][P + 1][r], C[P + 1][P + 1], 0, 0, 0);
         factor_diag(int_c<P + 1>{});
       }
-#pragma unroll
-      for (int I = P + 1; I < NRB; ++I) {
-#pragma unroll
-        for (int cb = 0; cb < NXB; ++cb)
-          if (SH::ownX(cb) == WV && !zero_tile(P, cb) && P == kfirst(cb)) X[I][cb] = x_initial(I, cb);
-        // does this wave (still) touch row block I?
-        bool any = false;
-#pragma unroll
-        for (int J = I; J < NRB; ++J) any = any || (SH::ownC(J) == WV && !(kOwnNext && I == P + 1 && J == P + 1));
-#pragma unroll
-        for (int cb = 0; cb < NXB; ++cb) any = any || (SH::ownX(cb) == WV && !zero_tile(P, cb));
-        if (any) {
-          const d4 v = tile_fetch(Vbuf + ((P & 1) * NRB + I) * SH::kTile, lane);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (16 * P + 4 * r < N) {
-              const double aop = v[r] * nrv[r];        // A[i][k] = -(V_pi[4r + k][i] / d_{4r + k})
-#pragma unroll
-              for (int J = I; J < NRB; ++J)
-                if (SH::ownC(J) == WV && !(kOwnNext && I == P + 1 && J == P + 1))
-                  C[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, C[P][J][r], C[I][J], 0, 0, 0);
-#pragma unroll
-              for (int cb = 0; cb < NXB; ++cb)
-                if (SH::ownX(cb) == WV && !zero_tile(P, cb))
-                  X[I][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, X[P][cb][r], X[I][cb], 0, 0, 0);
-            }
-          }
-        }
-      }
-      gram_step(pc, nrv);
+      trailing(pc, int_c<kOwnNext ? 1 : 0>{}, nrv);
       wg_barrier();      // the next diagonal tile is published; every wave is done with the V tiles of panel P
     }
   });
@@ -733,7 +775,8 @@ __device__ __forceinline__ double row16_sum(double v) {
 // The waves that hold no rows (4 .. 7) wait at the same barriers and read the verdict from an LDS word written in
 // front of each barrier (two slots by barrier parity): 0 go on, 1 done, 2 declined -- the direct path needs them.
 // Declines where the one-wave kernel's does: a diagonal entry of W <= kPresolveMinPivot (published as a NaN in the
-// first exchange, so that all waves see it), p.Wp <= 1e-10 r.r, no convergence to 1e-13 |x_c| in n - m + 10 steps.
+// first exchange, so that all waves see it), a Rayleigh quotient p.Wp / p.p <= 1e-6, no convergence to 1e-13 |x_c| in
+// n - m + 10 steps.
 template <class SH, int WV>
 __device__ __forceinline__ bool rs_cg_presolve(lds_f64 *const buf, lds_i32 *const verdict, const int lane, const bool isvar,
                                                const double (&Mrow)[SH::kRsLen], const double xc, const double gdiag, double &x0) {
@@ -798,8 +841,9 @@ __device__ __forceinline__ bool rs_cg_presolve(lds_f64 *const buf, lds_i32 *cons
     const double stop = kCgTolSquared * gamma;
     int code = 0;                                               // 1 done, 2 declined
     if (!(gamma > 0.0)) code = (gamma == 0.0) ? 1 : 2;          // x_c == 0: x0 = 0; NaN: decline (uniform: gamma is)
-    else if (!(delta > 1e-10 * gamma)) code = 2;
+    else if (!(delta > kCgMinRayleigh * gamma)) code = 2;         // (p = r: the Rayleigh quotient rule of cg_presolve)
     double alpha = gamma * fast_rcp(delta);
+    double pp = gamma;                                            // p.p by its recurrence (see cg_presolve)
     double p_own = r_own, q_own = w_own;
 #pragma unroll
     for (int q = 0; q < 4; ++q) qF[q] = wF[q];
@@ -816,7 +860,8 @@ __device__ __forceinline__ bool rs_cg_presolve(lds_f64 *const buf, lds_i32 *cons
       if (!(gamma_new > stop)) { code = (gamma_new <= stop) ? 1 : 2; break; }
       const double beta = gamma_new * fast_rcp(gamma);
       const double pwp = delta - beta * gamma_new * fast_rcp(alpha);      // p.Wp of the new direction
-      if (!(pwp > 1e-10 * gamma_new)) { code = 2; break; }                // (also NaN)
+      pp = fma(beta * beta, pp, gamma_new);
+      if (!(pwp > kCgMinRayleigh * pp)) { code = 2; break; }              // (also NaN)
       alpha = gamma_new * fast_rcp(pwp);
       p_own = fma(beta, p_own, r_own);
       q_own = fma(beta, q_own, w_own);

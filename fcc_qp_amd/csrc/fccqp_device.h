@@ -12,6 +12,10 @@ namespace fccqp {
 struct KernelArgs {
   int n;        // num_vars                      (reference fcc_qp.hpp:128)
   int m;        // num_equality_constraints      (:131)
+                // (The one-wave shape-specialised kernel takes its sizes from template parameters and never reads n / m /
+                // nc / s; its launchers put the number of its workgroups that are resident at once -- 4 x compute units:
+                // one_wave_resident_workgroups() -- into THIS field for the staggered start of fused_kernel.  A field of
+                // its own would cost that kernel 3 % through its kernarg layout, see the note on Q / A below.)
   int nc;       // contact force variables       (:129)
   int s;        // lambda_c_start                (:130)
   int batch;
@@ -186,6 +190,21 @@ constexpr int kSelfCheckAboveN = 256;
 long long cod_workspace_doubles_host(int n, int m);
 
 // ---- fused shape-specialised kernels (fccqp_fused.hip) ---------------------------------------
+// One-wave workgroups resident at once on the current device (four per compute unit: one per SIMD); cached per device.
+inline int one_wave_resident_workgroups() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+      (void)hipGetLastError();
+      cus = 256;
+    }
+    cached[dev] = 4 * cus;
+  }
+  return cached[dev];
+}
 bool fused_supported(int n, int m, int nc, int s);
 bool fused_pointers_ok(const KernelArgs &a);  // (always true since the tile loader: natural alignment suffices)
 // split == 0: the whole solve in one launch.  split == 2 or 3: the two-launch form -- fused_kernel<.., SPLIT> up to

@@ -26,7 +26,9 @@ bool matches(int n, int m, int nc, int s) {
 }
 template <class SH>
 hipError_t launch(const KernelArgs &a, hipStream_t stream) {
-  hipLaunchKernelGGL((fused::fused_kernel<SH, Storage>), dim3(a.batch), dim3(fused::kWave), 0, stream, a);
+  KernelArgs k = a;
+  k.m = one_wave_resident_workgroups();        // (staggered start of fused_kernel; the kernel's sizes are template parameters)
+  hipLaunchKernelGGL((fused::fused_kernel<SH, Storage>), dim3(a.batch), dim3(fused::kWave), 0, stream, k);
   return hipGetLastError();
 }
 hipError_t launch_by_shape(const KernelArgs &a, hipStream_t stream) {

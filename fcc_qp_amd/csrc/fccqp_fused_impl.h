@@ -1421,10 +1421,15 @@ __device__ __forceinline__ LaneInputs load_lane_inputs(const KernelArgs &a, cons
 // Returns false -- and the caller takes that direct path, with its own singularity rule and the COD hand-off -- when
 //   * the diagonal of W has an entry <= kPresolveMinPivot (every pivot of W's LDL^T is <= its diagonal entry: the direct
 //     path would declare K singular; a variable without cost or constraint -- the tested case -- shows exactly so),
-//   * a search direction has p.Wp <= 1e-10 r.r (a Rayleigh quotient that small means an eigenvalue that small), or
+//   * a search direction has a Rayleigh quotient p.Wp / p.p <= kCgMinRayleigh = 1e-6 (W has an eigenvalue at least that
+//     small: with the stop rule on the residual alone the component of x0 along it could be off by tolerance / 1e-6 and
+//     more -- ADVICE r4; the direct solve resolves it.  p.p costs no reduction: the residuals of the method are mutually
+//     orthogonal, so p.p = r.r + beta^2 p'.p' from the step before.  Through round 4: p.Wp <= 1e-10 r.r, which this
+//     implies since p.p >= r.r), or
 //   * the residual has not reached 1e-13 |x_c| after kCap iterations (ill-conditioned W).
 // On success x is x0 in the ADMM layout (this lane's variable).  vbuf is used for the exchange of p.
 constexpr double kCgTolSquared = 1e-26;
+constexpr double kCgMinRayleigh = 1e-6;
 template <class SH>
 __device__ __forceinline__ bool cg_presolve(lds_f64 *vbuf, const int lane, const bool isvar, const int var,
                                             const double (&Mrow)[SH::n], const double xc, const double gdiag, double &x) {
@@ -1437,6 +1442,7 @@ __device__ __forceinline__ bool cg_presolve(lds_f64 *vbuf, const int lane, const
   const double bb = rs;
   if (!(bb > 0.0)) { x = 0.0; return bb == 0.0; }            // x_c == 0: x0 = 0 (NaN: leave it to the direct path)
   const double stop = kCgTolSquared * bb;
+  double pp = rs;                                            // p.p (p = r)
   bool done = false;
 #pragma nounroll
   for (int it = 0; it < kCap; ++it) {
@@ -1452,7 +1458,7 @@ __device__ __forceinline__ bool cg_presolve(lds_f64 *vbuf, const int lane, const
     else dpp_matvec_pairs<0, n, NQ>(acc, Wq, Mrow);
     const double wp = p - acc;
     const double pwp = wave_sum(p * wp);
-    if (!(pwp > 1e-10 * rs)) break;                          // (also NaN)
+    if (!(pwp > kCgMinRayleigh * pp)) break;                 // (also NaN)
     const double alpha = rs * fast_rcp(pwp);
     xs = fma(alpha, p, xs);
     r = fma(-alpha, wp, r);
@@ -1460,6 +1466,7 @@ __device__ __forceinline__ bool cg_presolve(lds_f64 *vbuf, const int lane, const
     if (rs_new <= stop) { done = true; break; }
     const double beta = rs_new * fast_rcp(rs);
     p = fma(beta, p, r);
+    pp = fma(beta * beta, pp, rs_new);
     rs = rs_new;
   }
   lds_fence();
@@ -1664,13 +1671,15 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   const int lane = threadIdx.x;
   const int inst = block_instance(a);     // block -> instance map (fccqp_device.h)
   if (inst < 0) return;
-  // Staggered start.  A launch of several wave-rounds keeps the 1024 resident waves in lock step from the first load to
+  // Staggered start.  A launch of several wave-rounds keeps the resident waves (1024 on MI355X) in lock step from the first load to
   // the last store: the four waves of a CU reach every LDS-heavy piece (tile exchanges, the rho G image) and every
   // burst of global loads together, round after round.  Same-box A/B at batch 4096: starting the waves of SIMD k
   // k x 1.9 us late takes 2.7 % off the launch (W-sat; the phases then interleave, and the price is at most 5.6 us at
   // the end); 0.9 us steps gain 2.2 %, 3.7 us steps 2.7 %, 5.6 us steps 1.4 %.  Only the first round waits, and only
   // in launches of at least two rounds: a one-round launch would just end later.  (HW_REG_HW_ID bits 5:4: the SIMD.)
-  if (gridDim.x >= 2048u && blockIdx.x < 1024u) {
+  // (a.m: the number of workgroups resident at once, put there by the launcher -- see KernelArgs)
+  const unsigned resident = (unsigned)a.m;
+  if (gridDim.x >= 2u * resident && blockIdx.x < resident) {
     const int simd = (int)((__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11))) & 3);
     for (int k = 0; k < 4 * simd; ++k) __builtin_amdgcn_s_sleep(16);       // 16 x 64 cycles ~ 0.47 us
   }

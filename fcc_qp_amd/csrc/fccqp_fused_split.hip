@@ -17,8 +17,10 @@ bool matches(int n, int m, int nc, int s) {
 template <class SH>
 hipError_t launch(const KernelArgs &a, hipStream_t stream, bool qa_f32, int waves) {
   const dim3 grid(a.batch), block(fused::kWave);
-  if (qa_f32) hipLaunchKernelGGL((fused::fused_kernel<SH, float, true>), grid, block, 0, stream, a);
-  else hipLaunchKernelGGL((fused::fused_kernel<SH, double, true>), grid, block, 0, stream, a);
+  KernelArgs k = a;
+  k.m = one_wave_resident_workgroups();        // (staggered start of fused_kernel, see KernelArgs)
+  if (qa_f32) hipLaunchKernelGGL((fused::fused_kernel<SH, float, true>), grid, block, 0, stream, k);
+  else hipLaunchKernelGGL((fused::fused_kernel<SH, double, true>), grid, block, 0, stream, k);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (waves >= 3) hipLaunchKernelGGL((fused::admm_kernel<SH, 3>), grid, block, 0, stream, a);

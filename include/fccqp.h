@@ -162,7 +162,8 @@ int fccqp_set_presolve_fallback(fccqp_solver *s, int enabled);
  * fccqp_details.solve_time are measured from).  On by default.  A hipEventRecord in front of the kernel makes the
  * kernel wait for the stream to drain -- ~5 us per solve, 1.5 % of a 4096-instance walking-shape batch -- so a
  * caller that times its solves itself can switch it off: fccqp_last_kernel_ms then returns FCCQP_ERR_UNSUPPORTED
- * and solve_time of a device-pointer solve is 0.  (No counterpart in the reference, whose solve_time is a host
+ * and solve_time of a device-pointer solve is 0 (small synchronous host-pointer solves are timed on the host clock
+ * whatever this switch says, see fccqp_last_timing).  (No counterpart in the reference, whose solve_time is a host
  * chrono pair, src/fcc_qp.cpp:115,188.) */
 int fccqp_set_kernel_timing(fccqp_solver *s, int enabled);
 /* Self-check behind every solve: one more small launch that re-computes A_eq z - b_eq from the solve's inputs and
@@ -217,7 +218,15 @@ int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
 /* Host-pointer form: borrows the seven host arrays for the duration of the call (as the
  * reference borrows its Eigen::Ref arguments), copies them to the device, solves the whole
  * batch and waits.  n_friction = coefficients supplied PER INSTANCE (must be >= nc/3; the row
- * stride of friction_coeffs is n_friction). */
+ * stride of friction_coeffs is n_friction).
+ * Where the data goes through: arrays that are page-locked (hipHostMalloc, fccqp_host_register) are read by the DMA
+ * engines in place; anything else is copied by the CPU into page-locked buffers of the handle first (two 4 MiB bounce
+ * buffers, double-buffered against the DMA; small batches: one gather block) -- the GPU never addresses pageable caller
+ * memory.  (Handing pageable arrays of 1 MiB and more to hipMemcpy makes the HIP runtime page-lock the caller's pages on
+ * the fly and cache that lock by address; the two process aborts this library has seen -- a GPU memory fault on a heap
+ * address -- were on that path: DESIGN.md section 7.3.)  The same holds for every entry point that takes or fills a
+ * caller array: fccqp_solve_f32, fccqp_get_solution, fccqp_get_state / fccqp_set_state.  Pageable arrays cost a CPU
+ * copy (~10 GB/s); page-lock them, or use the device-pointer form, where the transfer rate matters. */
 int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
                 const double *b_eq, const double *friction_coeffs, int n_friction,
                 const double *lb, const double *ub);
@@ -225,8 +234,8 @@ int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double 
 /* Asynchronous host-pointer form: the copies and the kernel(s) are enqueued on the solver's own
  * stream and the call returns at once.  The seven host arrays must stay valid and unmodified until
  * fccqp_synchronize() / fccqp_get_solution() on this handle, and should be page-locked
- * (fccqp_host_register below, or hipHostMalloc) -- from pageable memory the HIP runtime copies
- * synchronously and nothing overlaps.  This is what lets a caller keep several handles in flight:
+ * (fccqp_host_register below, or hipHostMalloc) -- pageable arrays are copied by the CPU through the
+ * handle's bounce buffers inside the call (see fccqp_solve) and only the kernel overlaps.  This is what lets a caller keep several handles in flight:
  * the H2D copy of one batch, the kernel of another and the D2H copy of a third overlap (bench.py's
  * `end_to_end` leg; SURVEY.md 8d timing protocol).  n_friction must equal nc/3 here.
  * Small batches (staged inputs of at most 1 MiB, e.g. up to ~20 walking-shape instances) are gathered
@@ -307,7 +316,11 @@ int fccqp_last_kernel_ms(fccqp_solver *s, float *ms);
  *   FCCQP_TIMING_HOST_CLOCK     small synchronous host-pointer solves record no events (each costs ~5 us of stream
  *                               time): host clock from the launch to the completion of the device work, i.e. launch
  *                               latency, kernel, the copy of the results and, if an instance was flagged, the COD pass;
- *   FCCQP_TIMING_NONE           nothing was measured (fccqp_set_kernel_timing(s, 0)); *ms = 0. */
+ *   FCCQP_TIMING_NONE           nothing was measured: fccqp_set_kernel_timing(s, 0) and a solve that records events
+ *                               (device-pointer, asynchronous, or a large host-pointer batch); *ms = 0.  The switch
+ *                               is about the start-of-kernel EVENT: a small synchronous host-pointer solve records
+ *                               none anyway and keeps reporting its host clock (FCCQP_TIMING_HOST_CLOCK), which costs
+ *                               nothing. */
 enum { FCCQP_TIMING_NONE = 0, FCCQP_TIMING_DEVICE_EVENTS = 1, FCCQP_TIMING_HOST_CLOCK = 2 };
 int fccqp_last_timing(fccqp_solver *s, float *ms, int *measured_by);
 /* Mean device time (seconds) the instances of the last solve spent per phase (fused kernel; the generic

@@ -43,17 +43,19 @@ def cg_presolve(W, xc, n, m):
     x = np.zeros(n); r = xc.copy(); p = xc.copy(); rs = r @ r; bb = rs
     if bb == 0.0:
         return x, 0
+    pp = rs                                   # p.p by its recurrence (the residuals are mutually orthogonal)
     for it in range(1, (n - m if n > m else n) + 11):
         wp = W @ p
         pwp = p @ wp
-        if not pwp > 1e-10 * rs:
+        if not pwp > 1e-6 * pp:               # kCgMinRayleigh: an eigenvalue of W at least that small is in play
             return None, it
         alpha = rs / pwp
         x = x + alpha * p; r = r - alpha * wp
         rs_new = r @ r
         if rs_new <= 1e-26 * bb:
             return x, it
-        p = r + (rs_new / rs) * p; rs = rs_new
+        beta = rs_new / rs
+        p = r + beta * p; pp = rs_new + beta * beta * pp; rs = rs_new
     return None, it
 
 
@@ -153,3 +155,36 @@ def test_cg_presolve_declines_where_the_direct_path_would_call_k_singular():
     assert abs(W[j, j]) < 1e-10 and abs(xc[j]) < 1e-12
     x, its = cg_presolve(W, xc, n, m)
     assert x is None and its == 0
+
+
+def test_cg_presolve_declines_on_a_small_eigenvalue_it_can_see():
+    """a clustered spectrum plus ONE small eigenvalue whose eigenvector is not axis-aligned (the diagonal test
+    does not see it).  With the stop rule on the residual alone conjugate gradients accept an x0 whose component along
+    that eigenvector is off by tolerance / eigenvalue; the Rayleigh-quotient rule (p.Wp / p.p <= 1e-6, p.p by its
+    recurrence) declines as soon as a search direction feels the eigenvalue, and the direct path takes over.  The
+    recurrence for p.p is checked against the inner product itself on a well-conditioned W."""
+    rng = np.random.default_rng(7)
+    n, m = 60, 38
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.concatenate([np.ones(m), rng.uniform(0.3, 0.9, n - m - 1), [1e-8]])
+    W = (Qo * lam) @ Qo.T; W = 0.5 * (W + W.T)
+    assert np.min(np.diag(W)) > 1e-3                      # nothing on the diagonal gives the eigenvalue away
+    for comp in (1e-3, 1e-6):
+        xc = Qo[:, :-1] @ rng.standard_normal(n - 1) + comp * Qo[:, -1]
+        x, its = cg_presolve(W, xc, n, m)
+        assert x is None, (comp, its)                      # declined: the direct path (LDL^T of W) resolves the direction
+    # a component below the stop tolerance is invisible to any Krylov method started from x_c; what CG returns then is the
+    # solve on the complement, and K itself is singular to working precision there (cond(W) 1e8 at rho 5e-5 means a
+    # reduced-Hessian eigenvalue of 5e-13): outside the parity contract, stated in DESIGN.md
+    xc = Qo[:, :-1] @ rng.standard_normal(n - 1)
+    x, its = cg_presolve(W, xc, n, m)
+    assert x is not None and np.linalg.norm(W @ x - xc) <= 1e-12 * np.linalg.norm(xc)
+    # the recurrence for p.p against the inner product, on an ordinary W
+    lam2 = np.concatenate([np.ones(m), rng.uniform(0.05, 0.9, n - m)])
+    W2 = (Qo * lam2) @ Qo.T; W2 = 0.5 * (W2 + W2.T)
+    xc = rng.standard_normal(n)
+    r = xc.copy(); p = xc.copy(); rs = r @ r; pp = rs
+    for _ in range(15):
+        wp = W2 @ p; alpha = rs / (p @ wp); r = r - alpha * wp
+        rs_new = r @ r; beta = rs_new / rs; p = r + beta * p; pp = rs_new + beta * beta * pp; rs = rs_new
+        assert abs(pp - p @ p) <= 1e-8 * (p @ p)

@@ -137,6 +137,10 @@ def main(budget=120.0, seed=1, max_chains=None):
         if time.time() - t_print > 50:
             print(f"... {chains} chains, {solves} solves, {bad} broken, worst rel err {worst:.2e}", flush=True); t_print = time.time()
     print(f"fuzz_api: {chains} chains, {solves} solves, {bad} broken, worst rel err {worst:.2e}", flush=True)
+    if max_chains is not None and chains < max_chains and not bad:
+        # (a run bounded by a case count must reach it: a budget that cuts it short is a failure, not a shorter test)
+        print(f"fuzz: the time budget ended after {chains} of {max_chains} cases", flush=True)
+        return 2
     return 1 if bad else 0
 
 

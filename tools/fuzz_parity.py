@@ -92,6 +92,7 @@ def main(budget=120.0, seed=1, replay=(), max_cases=None):
         kernels = [CAPI.KERNEL_AUTO, CAPI.KERNEL_GENERIC]
         if dims in FUSED: kernels += [CAPI.KERNEL_FUSED, CAPI.KERNEL_FUSED_SPLIT]
         if dims in COOP: kernels += [CAPI.KERNEL_COOP]
+        if dims in COOP and dims[0] > 64: kernels += [CAPI.KERNEL_COOP_SPLIT]      # (the two-launch form: row-split shapes)
         kernel = kernels[int(rng.integers(len(kernels)))]
         nb = int(rng.choice([1, 2, 3, 7, 17, 64, 65, 130, 200, 1100, 2500]))
         if dims[0] > 64: nb = min(nb, 200)
@@ -173,6 +174,10 @@ def main(budget=120.0, seed=1, replay=(), max_cases=None):
         if time.time() - t_print > 50:
             print(f"... {cases} cases, {bad} broken, worst rel err {worst:.2e}", flush=True); t_print = time.time()
     print(f"fuzz: {cases} cases, {notable} notable, {bad} broken, worst rel err (non-singular) {worst:.2e}", flush=True)
+    if max_cases is not None and cases < max_cases and not bad and not replay:
+        # (a run bounded by a case count must reach it: a budget that cuts it short is a failure, not a shorter test)
+        print(f"fuzz: the time budget ended after {cases} of {max_cases} cases", flush=True)
+        return 2
     return 1 if bad else 0
 
 

@@ -82,6 +82,10 @@ def main(budget=60.0, seed=1, max_cases=None):
         except Exception as e:                              # noqa: BLE001
             bad += 1; print("ERROR batch", dims, repr(e), flush=True)
     print(f"fuzz_python: {cases} cases, {bad} broken, worst rel err {worst:.2e}", flush=True)
+    if max_cases is not None and cases < max_cases and not bad:
+        # (a run bounded by a case count must reach it: a budget that cuts it short is a failure, not a shorter test)
+        print(f"fuzz: the time budget ended after {cases} of {max_cases} cases", flush=True)
+        return 2
     return 1 if bad else 0
 
 

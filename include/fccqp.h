@@ -141,7 +141,21 @@ int fccqp_device_count(void);            /* number of HIP devices visible (0 if 
 
 /* ---- life cycle   (replaces FCCQP::FCCQP, reference src/fcc_qp.cpp:24-55) ------------------ */
 /* `batch` independent instances of one shape, resident on HIP device `device`.
- * The reference constructor is batch = 1. */
+ * The reference constructor is batch = 1.
+ * Size limit (the reference has none: it allocates any N x N, src/fcc_qp.cpp:38-41): num_vars +
+ * num_equality_constraints <= 512, FCCQP_ERR_UNSUPPORTED beyond.  512 is eight KKT rows per lane of the any-shape
+ * kernel; the reference's own shapes are N = 98 (its harness) and N = 174 (36 DoF, eight contacts).  A caller with a
+ * larger KKT system has two ways that keep this library: (i) eliminate the equality constraints on the host when
+ * they are what makes it large: pick num_equality_constraints variables x_d that carry neither a finite bound nor a
+ * contact force and whose columns A_d of A_eq are invertible (the accelerations of an operational-space QP, which the
+ * dynamics rows determine, are such a set), substitute x_d = A_d^-1 (b_eq - A_f x_f), and solve for the remaining
+ * variables x_f -- the bounded ones and lambda_c among them, still coordinates, so box and cone apply unchanged --
+ * with Q_f = [-A_d^-1 A_f; I]^T Q [-A_d^-1 A_f; I], the matching b_f and num_equality_constraints = 0 (served by the
+ * any-shape kernel); N drops by 2 num_equality_constraints, the minimiser is the same, the ADMM iterates on the way
+ * to it are not; (ii) split a block-diagonal problem -- several robots, several
+ * time steps without coupling -- into its blocks, which is what `batch` is for.  What this library does not do is
+ * factorise one dense KKT matrix beyond 512 rows: at that size the matrix (2 MB and more) no longer lives near the
+ * lanes that eliminate it, and a blocked out-of-core LDL^T is a different kernel, not a larger instance of this one. */
 int fccqp_create(int num_vars, int num_equality_constraints, int nc, int lambda_c_start,
                  int batch, int device, fccqp_solver **out);
 int fccqp_destroy(fccqp_solver *s);

@@ -100,6 +100,10 @@ struct fccqp_solver {
   int *fb_seen_dev = nullptr;
   int fb_full_left = kFbFullFor;
   long long work_stride = 0;
+  // block -> instance order of the one-wave kernel (fccqp_set_dispatch_order): longest-first from the previous solve's
+  // iteration counts, built on the device in front of the launch
+  int order_mode = FCCQP_ORDER_HASH;
+  int *dorder = nullptr;
   // two-launch forms (FCCQP_KERNEL_FUSED_SPLIT, FCCQP_KERNEL_COOP_SPLIT): rows of rho G + x_c, allocated on first use
   // (a handle's shape has at most one of the two forms in use at a time; the stride is the larger need seen so far)
   double *dsplit = nullptr;
@@ -472,6 +476,14 @@ int enqueue_impl(fccqp_solver *s, const double *dQ, const double *db, const doub
     s->kernel_used = split ? FCCQP_KERNEL_FUSED_SPLIT : FCCQP_KERNEL_FUSED;
     fccqp::KernelArgs af = a;
     if (split) { af.workspace = s->dsplit; af.workspace_stride = s->split_stride; }
+    // a chain's next solve, longest instance first: only where a launch runs in several rounds, and only with the
+    // iteration counts of a previous solve on this handle to go by (they are still in place: this launch overwrites them)
+    if (!split && s->order_mode == FCCQP_ORDER_PREVIOUS_ITERATIONS && s->solved && s->batch >= 8 * s->compute_units) {
+      if (!s->dorder) HIP_TRY(s, hipMalloc(reinterpret_cast<void **>(&s->dorder), sizeof(int) * (size_t)s->batch));
+      e = fccqp::launch_order_by_iterations(s->dniter, s->batch, s->dorder, stream);
+      if (e != hipSuccess) return fail(s, FCCQP_ERR_HIP, "dispatch-order kernel launch", e);
+      af.inst_list = s->dorder;
+    }
     e = fccqp::launch_fused(af, stream, qa_f32, split);
   } else {
     s->kernel_used = FCCQP_KERNEL_GENERIC;
@@ -782,7 +794,7 @@ int fccqp_destroy(fccqp_solver *s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   (void)hipGetLastError();
   void *ptrs[] = {s->wb, s->wbeq, s->wmu, s->wlb, s->wub, s->din_block, s->dres_block, s->dmux, s->dmulc,
-                  s->dwork, s->dphase, s->dfb_list, s->dfb_count, s->dcod_ws, s->dticket, s->dsplit};
+                  s->dwork, s->dphase, s->dfb_list, s->dfb_count, s->dcod_ws, s->dticket, s->dsplit, s->dorder};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (s->fb_seen) (void)hipHostFree(const_cast<int *>(s->fb_seen));
@@ -820,6 +832,11 @@ int fccqp_set_warm_start(fccqp_solver *s, int warm_start) {
 int fccqp_set_kernel(fccqp_solver *s, int kernel) {
   if (!s || kernel < FCCQP_KERNEL_AUTO || kernel > FCCQP_KERNEL_COOP_SPLIT) return FCCQP_ERR_INVALID_ARG;
   s->kernel_request = kernel;
+  return FCCQP_OK;
+}
+int fccqp_set_dispatch_order(fccqp_solver *s, int order) {
+  if (!s || (order != FCCQP_ORDER_HASH && order != FCCQP_ORDER_PREVIOUS_ITERATIONS)) return FCCQP_ERR_INVALID_ARG;
+  s->order_mode = order;
   return FCCQP_OK;
 }
 int fccqp_set_presolve_fallback(fccqp_solver *s, int enabled) {

@@ -40,6 +40,8 @@ struct KernelArgs {
   // list mode (generic kernel only, the fallback launch): for every instance in
   // inst_list[0..*inst_count) compute the COD x0 in cod_ws, then run ADMM from it; *next_count is
   // zeroed for the following solve (the two counters are used alternately: no memset)
+  // (one-wave kernel, batch launch: inst_list != nullptr with inst_count == nullptr is the block -> instance map of this
+  // launch -- block b solves instance inst_list[b] -- instead of the fixed permutation of block_instance())
   const int *inst_list;
   const int *inst_count;
   int *next_count;
@@ -183,6 +185,9 @@ hipError_t launch_widen5(const float *const src[5], double *const dst[5], const 
 // ---- self-check behind a solve (fccqp_check.hip): raises kFlagEqResidual on every instance whose z is not finite or
 // violates A_eq z = b_eq by more than `tol` relative to the terms of the row (a.A / a.b_eq: the solve's inputs, a.x: z)
 hipError_t launch_eq_residual_check(const KernelArgs &a, hipStream_t stream, bool qa_f32, double tol);
+// order[0 .. batch) = the instances sorted by n_iter (of the previous solve), longest first: the block -> instance map
+// of the one-wave kernel for the next solve of a chain (KernelArgs::inst_list with inst_count == nullptr)
+hipError_t launch_order_by_iterations(const int *n_iter, int batch, int *order, hipStream_t stream);
 // shapes whose solves are always checked (the global-workspace instantiations of the generic kernel beyond this size)
 constexpr int kSelfCheckAboveN = 256;
 

@@ -1669,8 +1669,16 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   lds_f64 *const vbuf = M + SH::kMat;
 
   const int lane = threadIdx.x;
-  const int inst = block_instance(a);     // block -> instance map (fccqp_device.h)
-  if (inst < 0) return;
+  // block -> instance map: the fixed permutation of fccqp_device.h, or -- the next solve of a chain -- the caller's
+  // longest-first order (launch_order_by_iterations)
+  int inst;
+  if (a.inst_list) {
+    if (blockIdx.x >= (unsigned)a.batch) return;
+    inst = __builtin_amdgcn_readfirstlane(a.inst_list[blockIdx.x]);
+  } else {
+    inst = block_instance(a);
+    if (inst < 0) return;
+  }
   // Staggered start.  A launch of several wave-rounds keeps the resident waves (1024 on MI355X) in lock step from the first load to
   // the last store: the four waves of a CU reach every LDS-heavy piece (tile exchanges, the rho G image) and every
   // burst of global loads together, round after round.  Same-box A/B at batch 4096: starting the waves of SIMD k

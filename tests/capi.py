@@ -17,6 +17,7 @@ KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FUSED, KERNEL_FUSED_SPLIT, KERNEL_COOP, KERN
 FLAG_PRESOLVE_RAN, FLAG_PRESOLVE_NUMERICAL, FLAG_ADMM_NUMERICAL, FLAG_EQUALITY_ONLY, FLAG_PRESOLVE_COD, FLAG_EQ_RESIDUAL, FLAG_PRESOLVE_CG = 1, 2, 4, 8, 16, 32, 64
 TIMING_NONE, TIMING_DEVICE_EVENTS, TIMING_HOST_CLOCK = 0, 1, 2
 ORIGIN_BUILTIN, ORIGIN_JIT, ORIGIN_GENERIC_ONLY = 0, 1, 2
+ORDER_HASH, ORDER_PREVIOUS_ITERATIONS = 0, 1
 
 
 class Options(C.Structure):
@@ -61,6 +62,7 @@ def lib():
         L.fccqp_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_set_kernel.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_set_presolve_fallback.argtypes = [C.c_void_p, C.c_int]
+        L.fccqp_set_dispatch_order.argtypes = [C.c_void_p, C.c_int]
         L.fccqp_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         if hasattr(L, "fccqp_set_self_check"):          # (older builds under FCCQP_LIB_PATH, tools/ab_bench.py)
             L.fccqp_set_self_check.argtypes = [C.c_void_p, C.c_int]
@@ -128,6 +130,9 @@ class Solver:
 
     def set_kernel(self, k):
         self._ck(self.L.fccqp_set_kernel(self.h, int(k)), "set_kernel")
+
+    def set_dispatch_order(self, order):
+        self._ck(self.L.fccqp_set_dispatch_order(self.h, int(order)), "set_dispatch_order")
 
     def set_presolve_fallback(self, on):
         self._ck(self.L.fccqp_set_presolve_fallback(self.h, int(bool(on))), "set_presolve_fallback")

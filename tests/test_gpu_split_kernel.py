@@ -119,3 +119,41 @@ def test_split_refused_without_a_fused_shape():
     B = P.Batch(np.stack([np.eye(10)] * 2), np.zeros((2, 10)), np.ones((2, 4, 10)), np.zeros((2, 4)), np.full((2, 1), 0.5),
                 np.full((2, 10), -np.inf), np.full((2, 10), np.inf))
     assert s.solve(*B.arrays()) == CAPI.ERR_UNSUPPORTED
+
+
+# ---- the block -> instance order of a chain's next solve (fccqp_set_dispatch_order) --------------------------------------
+def test_longest_first_order_changes_no_result():
+    """FCCQP_ORDER_PREVIOUS_ITERATIONS: block b of a warm-started solve takes the instance with the b-th largest iteration
+    count of the previous solve (a counting sort on the device in front of the launch).  Whatever the order, every
+    instance is solved exactly once and by the same instruction sequence: z, n_iter, duals and flags must be bit-identical
+    to the fixed permutation's, step after step of a chain whose inputs move."""
+    import torch
+    nb = 8 * torch.cuda.get_device_properties(0).multi_processor_count + 40        # (the order applies from 8 instances per CU on)
+    seq = P.gait_sequence(260)
+    offs = [(7 * c) % 250 for c in range(64)]
+
+    def batch_at(t):
+        base = P.stack([seq[o + t] for o in offs])
+        reps = -(-nb // 64)
+        return P.Batch(*(np.ascontiguousarray(np.tile(a, (reps,) + (1,) * (a.ndim - 1))[:nb]) for a in base.arrays()))
+    batches = [batch_at(t) for t in range(4)]
+    out = {}
+    for order in (CAPI.ORDER_HASH, CAPI.ORDER_PREVIOUS_ITERATIONS):
+        s = CAPI.Solver(*P.WALKING.ctor_args, batch=nb); s.set_options(**P.HARNESS_OPTIONS); s.set_dispatch_order(order)
+        steps = []
+        for t, B in enumerate(batches):
+            s.set_warm_start(t > 0)
+            s.solve_ok(*B.arrays())
+            z, d = s.solution()
+            steps.append((z, [x.n_iter for x in d], [x.flags for x in d], s.state()))
+        assert s.kernel() == CAPI.KERNEL_FUSED
+        out[order] = steps
+        s.close()
+    for t, (a, b) in enumerate(zip(out[CAPI.ORDER_HASH], out[CAPI.ORDER_PREVIOUS_ITERATIONS])):
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], f"step {t}"
+        for x, y in zip(a[3], b[3]):
+            assert np.array_equal(x, y), f"state at step {t}"
+    its = np.array(out[CAPI.ORDER_HASH][-1][1])
+    assert its.min() < 50 and its.max() == P.HARNESS_OPTIONS["max_iter"], "the chain mixes short and long instances"
+    s = CAPI.Solver(*P.WALKING.ctor_args, batch=4)
+    assert s.L.fccqp_set_dispatch_order(s.h, 7) == CAPI.ERR_INVALID_ARG

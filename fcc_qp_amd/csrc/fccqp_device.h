@@ -41,7 +41,8 @@ struct KernelArgs {
   // inst_list[0..*inst_count) compute the COD x0 in cod_ws, then run ADMM from it; *next_count is
   // zeroed for the following solve (the two counters are used alternately: no memset)
   // (one-wave kernel, batch launch: inst_list != nullptr with inst_count == nullptr is the block -> instance map of this
-  // launch -- block b solves instance inst_list[b] -- instead of the fixed permutation of block_instance())
+  // launch -- block b solves instance inst_list[b] -- instead of the fixed permutation of block_instance(); the launcher
+  // then takes fused_kernel<.., ORDERED = true>)
   const int *inst_list;
   const int *inst_count;
   int *next_count;

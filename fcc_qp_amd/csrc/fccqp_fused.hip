@@ -28,7 +28,9 @@ template <class SH>
 hipError_t launch(const KernelArgs &a, hipStream_t stream) {
   KernelArgs k = a;
   k.m = one_wave_resident_workgroups();        // (staggered start of fused_kernel; the kernel's sizes are template parameters)
-  hipLaunchKernelGGL((fused::fused_kernel<SH, Storage>), dim3(a.batch), dim3(fused::kWave), 0, stream, k);
+  // (a.inst_list: the caller's block -> instance order, served by an instantiation of its own)
+  if (a.inst_list) hipLaunchKernelGGL((fused::fused_kernel<SH, Storage, false, true>), dim3(a.batch), dim3(fused::kWave), 0, stream, k);
+  else hipLaunchKernelGGL((fused::fused_kernel<SH, Storage>), dim3(a.batch), dim3(fused::kWave), 0, stream, k);
   return hipGetLastError();
 }
 hipError_t launch_by_shape(const KernelArgs &a, hipStream_t stream) {

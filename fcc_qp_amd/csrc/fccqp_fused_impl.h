@@ -1661,7 +1661,10 @@ __device__ __forceinline__ void epilogue_writeback(const KernelArgs &a, const Ad
 // SPLIT = true is the first half of the two-launch form (FCCQP_KERNEL_FUSED_SPLIT): the kernel ends after the
 // presolve and leaves this lane's row of rho G, x_c (workspace, lane-major: 512-byte stores) and x0 (the
 // warm-start state) for admm_kernel below, which runs P4 + P5 at two or three waves per SIMD.
-template <class SH, class TIN, bool SPLIT = false>
+// ORDERED = true: block b solves instance a.inst_list[b] (the longest-first order of a chain's next solve,
+// launch_order_by_iterations) instead of the fixed permutation.  An instantiation of its own: the test of a.inst_list in
+// front of the whole-solve kernel cost the headline 0.6 % (same-box A/B of builds), for a feature it does not use.
+template <class SH, class TIN, bool SPLIT = false, bool ORDERED = false>
 __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   constexpr int n = SH::n, m = SH::m, nc = SH::nc, s0 = SH::s, N = SH::N;
   __shared__ __attribute__((aligned(16))) double lds_raw[SH::kLdsDoubles];
@@ -1672,7 +1675,7 @@ __global__ __launch_bounds__(kWave, 1) void fused_kernel(const KernelArgs a) {
   // block -> instance map: the fixed permutation of fccqp_device.h, or -- the next solve of a chain -- the caller's
   // longest-first order (launch_order_by_iterations)
   int inst;
-  if (a.inst_list) {
+  if constexpr (ORDERED) {
     if (blockIdx.x >= (unsigned)a.batch) return;
     inst = __builtin_amdgcn_readfirstlane(a.inst_list[blockIdx.x]);
   } else {

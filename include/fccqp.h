@@ -168,15 +168,18 @@ int fccqp_set_options(fccqp_solver *s, const fccqp_options *opt);
 int fccqp_get_options(const fccqp_solver *s, fccqp_options *opt);
 int fccqp_set_warm_start(fccqp_solver *s, int warm_start);
 int fccqp_set_kernel(fccqp_solver *s, int kernel);   /* FCCQP_KERNEL_* */
-/* Which instance the k-th workgroup of a batch launch solves (one-wave kernel, batches of at least eight instances per
- * compute unit; no effect elsewhere, and never an effect on results).  The workgroups of a launch take the SIMDs in
+/* Which instance the k-th workgroup of a batch launch solves (one-wave kernel of a shape compiled into the library,
+ * batches of at least eight instances per compute unit; no effect elsewhere, and never an effect on results).  The workgroups of a launch take the SIMDs in
  * order as slots fall free, and an instance is one indivisible job whose length goes with its iteration count:
  *   FCCQP_ORDER_HASH                 a fixed pseudo-random permutation (default): no structure of the batch -- every
  *                                    other instance easy, say -- lines up with the hardware's dealing order;
  *   FCCQP_ORDER_PREVIOUS_ITERATIONS  longest first, by the iteration counts of the PREVIOUS solve on this handle: for a
  *                                    chain of solves (the same robots a tick later, fcc_qp_test.py:77-89) the last
  *                                    count is a good guess at the next, and a launch then ends when its work runs out
- *                                    instead of a job's length later.  One ~5 us sorting launch per solve. */
+ *                                    instead of a job's length later.  One ~5 us sorting launch per solve.
+ *                                    Measured (profiles/r05_dispatch_order_ab.json): + 6 % on a batch that is half
+ *                                    short, half long instances; - 2 .. - 5 % where nearly all instances run the
+ *                                    same number of iterations (nothing to pack, the sort is pure cost). */
 enum { FCCQP_ORDER_HASH = 0, FCCQP_ORDER_PREVIOUS_ITERATIONS = 1 };
 int fccqp_set_dispatch_order(fccqp_solver *s, int order);
 /* Rank-deficient presolve fallback on the device (replaces the CompleteOrthogonalDecomposition

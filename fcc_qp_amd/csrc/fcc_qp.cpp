@@ -209,6 +209,10 @@ FCCQPBatchSolution FCCQPBatch::GetSolution() const {
 void FCCQPBatch::set_self_check(bool enabled) {
   check(fccqp_set_self_check(h_, enabled ? 1 : 0), h_, "FCCQPBatch::set_self_check");
 }
+void FCCQPBatch::set_dispatch_order_by_previous_iterations(bool enabled) {
+  check(fccqp_set_dispatch_order(h_, enabled ? FCCQP_ORDER_PREVIOUS_ITERATIONS : FCCQP_ORDER_HASH), h_,
+        "FCCQPBatch::set_dispatch_order_by_previous_iterations");
+}
 std::pair<float, int> FCCQPBatch::LastTiming() const {
   float ms = 0.f;
   int by = FCCQP_TIMING_NONE;

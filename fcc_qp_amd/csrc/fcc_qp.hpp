@@ -144,6 +144,9 @@ class FCCQPBatch {
   void set_kernel(int kernel);  // FCCQP_KERNEL_*
   void set_kernel_timing(bool enabled);  // fccqp_set_kernel_timing: the start event of every solve (on by default)
   void set_self_check(bool enabled);     // fccqp_set_self_check: A_eq z = b_eq re-checked behind every solve (FLAG_EQ_RESIDUAL)
+  // fccqp_set_dispatch_order: the next launch of a chain longest instance first, by the previous solve's iteration counts
+  // (one-wave kernel of a built-in shape, batches of >= 8 instances per compute unit; never an effect on results)
+  void set_dispatch_order_by_previous_iterations(bool enabled);
   int kernel_in_use() const;
   FCCQPOptions get_options() const { return options_; }
 

@@ -305,6 +305,9 @@ PYBIND11_MODULE(fcc_qp_solver, m) {
       .def("set_self_check", &FCCQPBatch::set_self_check, py::arg("enabled"),
            "re-check A_eq z = b_eq behind every solve (flag FLAG_EQ_RESIDUAL); default: on for num_vars + "
            "num_equality_constraints > 256")
+      .def("set_dispatch_order_by_previous_iterations", &FCCQPBatch::set_dispatch_order_by_previous_iterations, py::arg("enabled"),
+           "fccqp_set_dispatch_order: block -> instance order of the next launch of a chain, longest instance first by the "
+           "previous solve's iteration counts (opt-in; results never depend on it)")
       .def("AlgorithmicBytes", &FCCQPBatch::AlgorithmicBytes)
       .def("device_pointers",
            [](FCCQPBatch &self) {

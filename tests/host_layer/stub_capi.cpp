@@ -51,6 +51,7 @@ int fccqp_set_kernel(fccqp_solver *s, int k) { s->kernel = k; return FCCQP_OK; }
 int fccqp_set_presolve_fallback(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_set_kernel_timing(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_set_self_check(fccqp_solver *, int) { return FCCQP_OK; }
+int fccqp_set_dispatch_order(fccqp_solver *, int) { return FCCQP_OK; }
 int fccqp_get_kernel(const fccqp_solver *s, int *k) { *k = s->kernel; return FCCQP_OK; }
 int fccqp_kernel_for_shape(int, int, int, int) { return FCCQP_KERNEL_GENERIC; }
 int fccqp_get_shape(const fccqp_solver *s, int *n, int *m, int *nc, int *st, int *b, int *d) {

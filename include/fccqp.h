@@ -254,7 +254,8 @@ int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
  * the fly and cache that lock by address; the two process aborts this library has seen -- a GPU memory fault on a heap
  * address -- were on that path: DESIGN.md section 7.3.)  The same holds for every entry point that takes or fills a
  * caller array: fccqp_solve_f32, fccqp_get_solution, fccqp_get_state / fccqp_set_state.  Pageable arrays cost a CPU
- * copy (~10 GB/s); page-lock them, or use the device-pointer form, where the transfer rate matters. */
+ * copy (measured: 26 GB/s into the device against 51 GB/s from page-locked arrays, 0.54 against 1.04 M walking-shape
+ * solves/s at batch 4096); page-lock them, or use the device-pointer form, where the transfer rate matters. */
 int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
                 const double *b_eq, const double *friction_coeffs, int n_friction,
                 const double *lb, const double *ub);

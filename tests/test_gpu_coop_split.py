@@ -48,14 +48,17 @@ def test_two_launches_equal_one_launch_and_the_oracle(oracle, workload):
                                      dict(max_iter=0, rho=5e-5, eps_fcone=1e-6, eps_bound=1e-6),
                                      dict(max_iter=1, rho=1e-3, eps_fcone=1e-3, eps_bound=1e-3),
                                      dict(max_iter=300, rho=0.1, eps_fcone=1e-3, eps_bound=1e-3)])
-def test_option_sets_random_population(oracle, options):
-    B = random_batch(LARGE, 24, seed=17 + options["max_iter"])
-    one = gpu(LARGE, options, B, CAPI.KERNEL_COOP, warm_steps=1)
-    two = gpu(LARGE, options, B, CAPI.KERNEL_COOP_SPLIT, warm_steps=1)
+@pytest.mark.parametrize("dims", [LARGE, (70, 20, 9, 40)], ids=["n114_eight_waves", "n70_four_waves"])
+def test_option_sets_random_population(oracle, options, dims):
+    """Both listed shapes with more than 64 variables: FCCQP(114, 60, 24, 66) (eight waves in the first launch, 29 / 29 /
+    28 / 28 variables per ADMM wave) and FCCQP(70, 20, 9, 40) (four waves, ragged second row half, three contacts)."""
+    B = random_batch(dims, 24, seed=17 + options["max_iter"])
+    one = gpu(dims, options, B, CAPI.KERNEL_COOP, warm_steps=1)
+    two = gpu(dims, options, B, CAPI.KERNEL_COOP_SPLIT, warm_steps=1)
     assert_same_bits(one, two, str(options))
     assert all(x.flags & CAPI.FLAG_PRESOLVE_CG for x in two[0][2])
-    z_ref, it_ref, _ = oracle_batch(oracle, LARGE, options, B)
-    assert_parity(two[0][0], two[0][1], z_ref, it_ref, tol=Z_TOL_TIGHT, what=f"coop_split {options}")
+    z_ref, it_ref, _ = oracle_batch(oracle, dims, options, B)
+    assert_parity(two[0][0], two[0][1], z_ref, it_ref, tol=Z_TOL_TIGHT, what=f"coop_split {dims} {options}")
 
 
 @pytest.mark.parametrize("rho", [100.0, 1e4])

@@ -1,11 +1,11 @@
 """Device phase stamps of one kernel on one shape at one batch size:
-    python tools/phase_probe.py <walking|large> <coop|coop_split|fused|generic|split> <batch> [W-sat] [max_iter]"""
+    python tools/phase_probe.py <walking|large|mid> <coop|coop_split|fused|generic|split> <batch> [W-sat] [max_iter]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fcc_qp_amd import problems as P
 from tests import capi as C
-shape = {"walking": P.WALKING, "large": P.LARGE}[sys.argv[1]]
+shape = {"walking": P.WALKING, "large": P.LARGE, "mid": P.MID}[sys.argv[1]]
 kern = {"coop": C.KERNEL_COOP, "fused": C.KERNEL_FUSED, "generic": C.KERNEL_GENERIC, "split": C.KERNEL_FUSED_SPLIT, "coop_split": C.KERNEL_COOP_SPLIT}[sys.argv[2]]
 nb = int(sys.argv[3])
 wl = sys.argv[4] if len(sys.argv) > 4 else "W-sat"
@@ -26,7 +26,7 @@ else:
     import ctypes, torch
     dev = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda() for a in B.arrays()]
     ptr = [ctypes.c_void_p(t.data_ptr()) for t in dev]
-    for _ in range(200):
+    for _ in range(int(os.environ.get("PROBE_REPS", "200"))):
         assert s.L.fccqp_solve_device(s.h, *ptr, ctypes.c_void_p(-1)) == 0
     assert s.L.fccqp_synchronize(s.h) == 0
     ms = [s.kernel_ms()] * 5

@@ -390,6 +390,119 @@ __device__ bool ldlt_factor_share(lds_f64 *M, int N, int lane, int part, int par
   return bad;
 }
 
+// ---- the same factorisation by PANELS of kGP columns (matrix in global memory, N <= 256) ---------------------------------
+// The routine below (ldlt_factor on a global pointer) eliminates one column at a time and reads, updates and writes back
+// the whole trailing matrix for each: N^3 / 6 entries x 16 bytes = 29 MB of traffic per factorisation at N = 222, 60 GB for
+// the 1024 QPs a chip holds at once -- 11 ms, HBM-bound, twice per cold solve (tools/phase_probe.py mid generic).  Here
+// kGP = 8 columns are eliminated among themselves first (their trailing columns inside the panel updated column by column,
+// the multipliers l_ik and the unscaled column entries a_ik kept in registers: 2 x 8 x SLOTS doubles), and the rest of the
+// matrix then takes all eight updates in ONE pass: M[i][j] -= sum_k l_ik a_jk, with a_jk from lane j by v_readlane.  Same
+// row ownership (every entry is read and written by one lane only), same pivots, same Eigen rules (a zero / non-finite
+// pivot leaves its column unscaled; `tiny` as below); the sums associate differently (eight products, then one
+// subtraction per panel instead of eight rounded subtractions).
+constexpr int kGP = 8;
+template <int SLOTS>
+__device__ bool ldlt_factor_panels(double *M, const int N, const int lane, const double tiny) {
+  static_assert(SLOTS <= 4, "2 x kGP x SLOTS doubles of panel state: four slots at most");
+  constexpr int U = 4;
+  bool bad_any = false;
+  int row[SLOTS];
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) row[t] = lane + kWave * t;
+  for (int k0 = 0; k0 < N; k0 += kGP) {
+    const int kp = (N - k0 < kGP) ? N - k0 : kGP;         // columns in this panel
+    double A[kGP][SLOTS], Lm[kGP][SLOTS];                  // unscaled column entries (rows >= k), multipliers (rows > k)
+#pragma unroll
+    for (int q = 0; q < kGP; ++q)
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) { A[q][t] = 0.0; Lm[q][t] = 0.0; }
+    // ---- the panel's own columns, one at a time; column k0 + q has taken the updates of the columns left of it --------
+#pragma unroll
+    for (int q = 0; q < kGP; ++q) {
+      if (q < kp) {
+        const int k = k0 + q;
+        const int ck = col_base(k, N);
+        const int tk = k >> 6, lk = k & (kWave - 1);
+        double dsel = 0.0;
+        double cp[kGP];                                    // a_kp of row k for the panel's earlier columns p < q
+#pragma unroll
+        for (int p = 0; p < q; ++p) {
+          double c = 0.0;
+#pragma unroll
+          for (int t2 = 0; t2 < SLOTS; ++t2) {
+            const double b = lane_bcast(A[p][t2], lk);
+            c = (t2 == tk) ? b : c;
+          }
+          cp[p] = c;
+        }
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+          double v = (row[t] >= k && row[t] < N) ? M[ck + row[t]] : 0.0;
+#pragma unroll
+          for (int p = 0; p < q; ++p) v = fma(-Lm[p][t], cp[p], v);
+          A[q][t] = (row[t] >= k) ? v : 0.0;
+          dsel = (t == tk) ? A[q][t] : dsel;
+        }
+        const double d = lane_bcast(dsel, lk);
+        const bool bad = !(fabs(d) > 0.0) || !(fabs(d) <= DBL_MAX);
+        bad_any |= bad || !(fabs(d) > tiny);
+#pragma unroll
+        for (int t = 0; t < SLOTS; ++t) {
+          const double v = (row[t] > k) ? A[q][t] : 0.0;
+          Lm[q][t] = bad ? v : v / d;                      // Eigen: A21 /= pivot only when the pivot is non-zero
+          if (row[t] > k && row[t] < N) M[ck + row[t]] = Lm[q][t];
+          else if (row[t] == k) M[ck + row[t]] = A[q][t];  // the pivot itself (it has taken the panel's updates)
+        }
+      }
+    }
+    // ---- the columns right of the panel take its kp updates in one pass ------------------------------------------------
+    const int kend = k0 + kp;
+#pragma unroll
+    for (int tj = 0; tj < SLOTS; ++tj) {
+      const int jbase = kWave * tj;
+      if (jbase + kWave > kend && jbase < N) {             // wave-uniform: this slot holds columns >= kend
+        const int jl0 = (kend > jbase) ? kend - jbase : 0;
+        const int jl1 = (N - jbase < kWave) ? N - jbase : kWave;
+        for (int jl = jl0; jl < jl1; jl += U) {
+          double v[U][SLOTS];
+          int cj[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int jlu = (jl + u < jl1) ? jl + u : jl1 - 1;
+            cj[u] = col_base(jbase + jlu, N);
+#pragma unroll
+            for (int t2 = tj; t2 < SLOTS; ++t2) {
+              const int j = jbase + jlu;
+              v[u][t2] = (row[t2] >= j && row[t2] < N) ? M[cj[u] + row[t2]] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int jlu = (jl + u < jl1) ? jl + u : jl1 - 1;
+#pragma unroll
+            for (int q = 0; q < kGP; ++q) {
+              const double c = (jl + u < jl1) ? lane_bcast(A[q][tj], jlu) : 0.0;      // a_jq of row j (zero beyond the panel's kp)
+#pragma unroll
+              for (int t2 = tj; t2 < SLOTS; ++t2) v[u][t2] = fma(-Lm[q][t2], c, v[u][t2]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int j = jbase + jl + u;
+            if (jl + u < jl1) {
+#pragma unroll
+              for (int t2 = tj; t2 < SLOTS; ++t2)
+                if (row[t2] >= j && row[t2] < N) M[cj[u] + row[t2]] = v[u][t2];
+            }
+          }
+        }
+      }
+    }
+  }
+  return bad_any;
+}
+
+
 // Unpivoted LDL^T in place (right-looking), natural order: the variant for matrices that do not
 // fit in LDS (global workspace, N > 198).  Returns true if a pivot was zero, not finite or, in
 // magnitude, <= tiny (the situation in which Eigen's info() != Success can arise, fcc_qp.cpp:164;
@@ -406,6 +519,7 @@ __device__ bool ldlt_factor_share(lds_f64 *M, int N, int lane, int part, int par
 // left as read-modify-write statements it compiles to one load / wait / store round trip each.
 template <int SLOTS>
 __device__ bool ldlt_factor(double *M, int N, int lane, const double tiny) {
+  if constexpr (SLOTS <= 4) return ldlt_factor_panels<SLOTS>(M, N, lane, tiny);     // (round 5: rank-8 updates, see there)
   constexpr int U = 4;
   bool bad_any = false;
   int row[SLOTS];

@@ -446,3 +446,27 @@ def test_kernel_timing_switch():
     s.set_kernel_timing(True)
     F.solve_tensors(s, *tens); torch.cuda.synchronize()
     assert s.LastKernelMilliseconds() > 0.0 and s.GetSolution()[0].details.solve_time > 0.0
+
+
+def test_batch_class_dispatch_order_switch():
+    """FCCQPBatch.set_dispatch_order_by_previous_iterations (fccqp_set_dispatch_order): a chain's next launch longest
+    instance first.  Results never depend on the order: two warm-started steps with the switch on and off, bit for bit."""
+    import torch
+    import fcc_qp_amd as F
+    nb = 8 * torch.cuda.get_device_properties(0).multi_processor_count        # (where the order applies)
+    base = P.workload("W-mix", nb, P.WALKING, distinct=64)
+    moved = P.Batch(*[a.copy() for a in base.arrays()])
+    moved.b[:] = moved.b + 0.03 * np.random.default_rng(1).standard_normal(moved.b.shape)
+    out = []
+    for on in (False, True):
+        s = F.FCCQPBatch(60, 38, 12, 38, nb, 0)
+        s.set_options(harness_options(F))
+        s.set_dispatch_order_by_previous_iterations(on)
+        s.Solve(*base.arrays())
+        s.set_warm_start(True)
+        s.Solve(*moved.arrays())
+        sol = s.GetSolution()
+        out.append((np.asarray(sol.z).copy(), np.asarray(sol.n_iter).copy()))
+        assert s.kernel_in_use() == F.KERNEL_FUSED
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert len(set(out[0][1].tolist())) > 1

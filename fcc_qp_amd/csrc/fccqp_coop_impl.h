@@ -1188,7 +1188,7 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
       const lds_f64 *img = L + SH::kBig;
       xc = isvar ? rhs[vi] : 0.0;
       if constexpr (kRS) gdiag = isvar ? img[vi * n + vi] : 0.0;
-      if constexpr (kAdmmWave && kRS) {
+      if constexpr (kAdmmWave && kRS && !SPLIT) {
         // entry e of block k: the variable in slot 16 (k & 1) + e of wave 2 half + (k >> 1) -- its column of this row
         constexpr int LO = SH::kRsOdd;
         static_for<0, SH::kRsLen>([&](auto ec) {
@@ -1208,13 +1208,28 @@ __device__ __forceinline__ void coop_wave(const KernelArgs &a, const int inst, l
     }
     if constexpr (SPLIT) {
       // ---- hand-over to coop_admm_kernel (SplitWorkspace) -------------------------------------------------------------
-      if constexpr (kAdmmWave) {
+      // (every wave of the workgroup takes part: with eight waves, wave w + 4 has the lane roles of ADMM wave w and
+      // gathers the second half of its entries out of the image -- the four waves that would otherwise only wait)
+      {
         using WS = SplitWorkspace<SH>;
         double *ws = a.workspace + (size_t)inst * (size_t)a.workspace_stride;
-#pragma unroll
-        for (int e = 0; e < SH::kRsLen; ++e) ws[WS::kRowsOff + ((WV & 3) * SH::kRsLen + e) * 64 + lane] = Mrow[e];
-        ws[WS::kXcOff + (WV & 3) * 64 + lane] = xc;
-        ws[WS::kGdOff + (WV & 3) * 64 + lane] = gdiag;
+        const lds_f64 *img = L + SH::kBig;
+        constexpr int kParts = SH::W / 4, part = WV / 4, LO = SH::kRsOdd;
+        constexpr int e_lo = (SH::kRsLen * part) / kParts, e_hi = (SH::kRsLen * (part + 1)) / kParts;
+        static_for<e_lo, e_hi>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          constexpr int k = (e < 16) ? 0 : ((e < 16 + LO) ? 1 : ((e < 32 + LO) ? 2 : 3));
+          constexpr int i = e - ((k == 0) ? 0 : ((k == 1) ? 16 : ((k == 2) ? 16 + LO : 32 + LO)));
+          constexpr int p0 = 32 * (k >> 1) + 16 * (k & 1) + i;                  // position in the lower half's columns
+          constexpr int v0 = RS::pos_variable(p0), v1 = RS::pos_variable(64 + p0);
+          const int cv = half ? v1 : v0;
+          const double g = img[vi * n + ((cv >= 0) ? cv : 0)];
+          ws[WS::kRowsOff + ((WV & 3) * SH::kRsLen + e) * 64 + lane] = (isvar && cv >= 0) ? g : 0.0;
+        });
+        if constexpr (part == 0) {
+          ws[WS::kXcOff + (WV & 3) * 64 + lane] = xc;
+          ws[WS::kGdOff + (WV & 3) * 64 + lane] = gdiag;
+        }
       }
       if (WV == 0 && lane == 0) {
         a.flags[inst] = flags;

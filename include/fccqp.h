@@ -248,14 +248,14 @@ int fccqp_get_shape(const fccqp_solver *s, int *num_vars, int *num_eq, int *nc,
  * batch and waits.  n_friction = coefficients supplied PER INSTANCE (must be >= nc/3; the row
  * stride of friction_coeffs is n_friction).
  * Where the data goes through: arrays that are page-locked (hipHostMalloc, fccqp_host_register) are read by the DMA
- * engines in place; anything else is copied by the CPU into page-locked buffers of the handle first (two 4 MiB bounce
+ * engines in place; anything else is copied by the CPU into page-locked buffers of the handle first (two 8 MiB bounce
  * buffers, double-buffered against the DMA; small batches: one gather block) -- the GPU never addresses pageable caller
  * memory.  (Handing pageable arrays of 1 MiB and more to hipMemcpy makes the HIP runtime page-lock the caller's pages on
  * the fly and cache that lock by address; the two process aborts this library has seen -- a GPU memory fault on a heap
  * address -- were on that path: DESIGN.md section 7.3.)  The same holds for every entry point that takes or fills a
  * caller array: fccqp_solve_f32, fccqp_get_solution, fccqp_get_state / fccqp_set_state.  Pageable arrays cost a CPU
- * copy (measured: 26 GB/s into the device against 51 GB/s from page-locked arrays, 0.54 against 1.04 M walking-shape
- * solves/s at batch 4096); page-lock them, or use the device-pointer form, where the transfer rate matters. */
+ * copy by up to four threads (measured: 42 GB/s into the device against 52 GB/s from page-locked arrays, 0.86 against
+ * 1.06 M walking-shape solves/s at batch 4096); page-lock them, or use the device-pointer form, where the transfer rate matters. */
 int fccqp_solve(fccqp_solver *s, const double *Q, const double *b, const double *A_eq,
                 const double *b_eq, const double *friction_coeffs, int n_friction,
                 const double *lb, const double *ub);
